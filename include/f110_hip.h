@@ -1,0 +1,171 @@
+/*
+ * f110_hip.h -- C ABI of the MI355X-native batched F1TENTH step path.
+ *
+ * This is the drop-in boundary for the reference's hot path
+ *   F110Env.step / reset          gym/f110_gym/envs/f110_env.py:261-347
+ *   Simulator.step / reset        gym/f110_gym/envs/base_classes.py:546-623
+ *   ScanSimulator2D.scan/set_map  gym/f110_gym/envs/laser_models.py:383-454
+ * The reference has no FFI layer (it is Python + Numba); these are the entry
+ * points a ctypes binding of that path needs (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative F110_E_* code and never
+ *     throws; f110_last_error() gives the message of the calling thread's last
+ *     failure.
+ *   - plain pointers and sizes only.  "dev" pointers are device (HBM) addresses
+ *     owned by the caller (e.g. torch tensors' data_ptr()); "host" pointers are
+ *     read during the call and not retained.  Nothing is allocated in
+ *     f110_step/f110_reset; kernels are enqueued on `stream` (a hipStream_t
+ *     passed as void*, NULL = default stream) and the call does not synchronise.
+ *   - a handle is bound to one device and is not thread-safe.
+ *   - all arithmetic that decides an index, a collision or a lap toggle is
+ *     IEEE fp64 in the reference's operation order (no FMA contraction).
+ */
+#ifndef F110_HIP_H
+#define F110_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define F110_OK 0
+#define F110_E_INVALID (-1)  /* bad argument / state (ValueError in the reference) */
+#define F110_E_HIP (-2)      /* HIP runtime failure */
+#define F110_E_NOMAP (-3)    /* scan before set_map (laser_models.py:445-446) */
+#define F110_E_INDEX (-4)    /* agent index out of range (base_classes.py:525-527) */
+#define F110_E_UNBOUND (-5)  /* step/reset before f110_bind */
+
+#define F110_MAX_AGENTS 8
+#define F110_NUM_PARAMS 18
+#define F110_RK4 1   /* Integrator.RK4   base_classes.py:40-42 */
+#define F110_EULER 2 /* Integrator.Euler */
+
+typedef struct f110_handle f110_handle;
+
+/* Constructor arguments of F110Env (f110_env.py:100-157), Simulator
+ * (base_classes.py:459) and ScanSimulator2D (laser_models.py:360), plus the
+ * batch extension (num_envs, autoreset, device). */
+typedef struct {
+    int32_t num_envs;    /* B: independent envs on this device */
+    int32_t num_agents;  /* A: cars per env (1..F110_MAX_AGENTS) */
+    int32_t num_beams;   /* 1080 */
+    int32_t theta_dis;   /* 2000 */
+    int32_t integrator;  /* F110_RK4 | F110_EULER */
+    int32_t ego_idx;
+    int32_t device;      /* HIP device ordinal */
+    int32_t autoreset;   /* 1: an env that reports done is reset to its spawn pose by the next f110_step */
+    double fov;          /* 2*pi */
+    double eps;          /* 1e-4 */
+    double max_range;    /* 30.0 */
+    double timestep;     /* 0.01 */
+    double ttc_thresh;   /* 0.005 (base_classes.py:113) */
+    /* mu C_Sf C_Sr lf lr h m I s_min s_max sv_min sv_max v_switch a_max v_min v_max width length */
+    double params[F110_NUM_PARAMS];
+} f110_config;
+
+/* Caller-owned device buffers the step reads and writes (N = B*A cars).
+ * Simulation state (carried from step to step): */
+typedef struct {
+    double *state;          /* [N,7]  x y steer v yaw yaw_rate slip   base_classes.py:95-96 */
+    double *steer_buf;      /* [N,2]  steering delay FIFO, [0] newest  :269-276 */
+    int32_t *steer_cnt;     /* [N]    entries in the FIFO (0..2) */
+    int32_t *noise_step;    /* [N]    scans drawn since the car's reset (row of the noise table) */
+    double *spawn;          /* [N,3]  pose used by reset / autoreset */
+    double *start_rot;      /* [B,4]  f110_env.py:329 */
+    uint8_t *near_start;    /* [N]    f110_env.py:182 */
+    int32_t *toggles;       /* [N]    f110_env.py:183 toggle_list */
+    double *current_time;   /* [B]    f110_env.py:177 */
+    uint8_t *pending_reset; /* [B]    1: next f110_step performs reset(spawn) + zero-action step for this env */
+    /* observations (overwritten every step): */
+    float *scans;           /* [N,num_beams] fp32 lidar ranges (noise, opponents applied) */
+    double *scans_f64;      /* [N,num_beams] same in fp64, or NULL to skip (parity tests, single-env facade) */
+    double *pose_snap;      /* [N,3]  poses after integration, before iTTC zeroing (base_classes.py:567) */
+    uint8_t *collisions;    /* [N]    obs['collisions'] (GJK or iTTC)  :543,:581-582 */
+    int32_t *collision_idx; /* [N]    Simulator.collision_idx, -1 = none */
+    uint8_t *in_collision;  /* [N]    RaceCar.in_collision (iTTC only) */
+    int32_t *lap_counts;    /* [N]    f110_env.py:238 */
+    double *lap_times;      /* [N]    f110_env.py:240 */
+    uint8_t *done;          /* [B]    f110_env.py:242 */
+    uint32_t *lookups;      /* [N]    distance-table reads of this step per car (instrumentation), or NULL */
+} f110_buffers;
+
+int f110_create(const f110_config *cfg, f110_handle **out);
+void f110_destroy(f110_handle *h);
+const char *f110_last_error(void);
+
+/* Simulator.update_params (base_classes.py:507-527): params shared by all cars. */
+int f110_update_params(f110_handle *h, const double *params18_host);
+
+/* Optional: replace the library's libm-computed tables by the caller's
+ * (numpy-computed, as in the reference).  sines/cosines: [theta_dis]
+ * (laser_models.py:379-381); scan_angles/beam_cosines/side_distances:
+ * [num_beams] (base_classes.py:123-156).  Any pointer may be NULL = keep. */
+int f110_set_tables(f110_handle *h, const double *sines_host, const double *cosines_host,
+                    const double *scan_angles_host, const double *beam_cosines_host,
+                    const double *side_distances_host);
+
+/* ScanSimulator2D.set_map (laser_models.py:383-427) after image decoding.
+ * free_mask: [H*W] row-major, row 0 = bottom of the image (already flipped,
+ * :399), nonzero = free (>128, :403-404).  The library runs an exact Euclidean
+ * distance transform (replaces scipy.ndimage.distance_transform_edt, :52). */
+int f110_set_map_occupancy(f110_handle *h, const uint8_t *free_mask_host, int32_t height,
+                           int32_t width, double resolution, double orig_x, double orig_y,
+                           double orig_c, double orig_s);
+/* Same, from a precomputed distance table dt = resolution*edt(img) (host, [H*W] fp64). */
+int f110_set_map_dt(f110_handle *h, const double *dt_host, int32_t height, int32_t width,
+                    double resolution, double orig_x, double orig_y, double orig_c, double orig_s);
+/* Copies the fp64 distance table the handle holds to the host (tests). */
+int f110_get_map_dt(f110_handle *h, double *dt_host_out);
+
+/* Exact squared Euclidean distance transform on the host (cells to nearest
+ * zero cell), the integer kernel behind f110_set_map_occupancy. */
+int f110_edt_squared(const uint8_t *free_mask_host, int32_t height, int32_t width, uint32_t *d2_out_host);
+
+/* Lidar noise: table[k] = k-th `rng.normal(0, std, num_beams)` draw of
+ * default_rng(seed) (laser_models.py:450-452, base_classes.py:202), [T,num_beams]
+ * fp64 on the host.  T = 0 / NULL switches noise off.  A car whose noise_step
+ * reaches T reads row noise_step % T (the host grows the table before that). */
+int f110_set_noise_table(f110_handle *h, const double *table_host, int64_t T);
+
+int f110_bind(f110_handle *h, const f110_buffers *bufs);
+
+/* F110Env.reset(poses) (f110_env.py:304-347) for the envs selected by mask
+ * (dev [B] uint8, NULL = all): stores poses as spawn, resets those envs and
+ * runs their zero-action step; other envs are untouched.  poses: dev [B,A,3]. */
+int f110_reset(f110_handle *h, const double *poses_dev, const uint8_t *mask_dev, void *stream);
+
+/* F110Env.step(action) for all B envs (f110_env.py:261-302).  actions: dev
+ * [B,A,2] fp64, column 0 = steer, column 1 = speed.  Envs with pending_reset
+ * ignore their action and perform reset(spawn) + zero-action step instead. */
+int f110_step(f110_handle *h, const double *actions_dev, void *stream);
+
+/* ---- function-level entry points (parity tests; all pointers dev) ---- */
+/* ScanSimulator2D.scan(pose, None): n poses [n,3] -> [n,num_beams] (noise off).
+ * scans_f32 / lookups may be NULL. */
+int f110_scan(f110_handle *h, const double *poses, int32_t n, double *scans_f64, float *scans_f32,
+              uint32_t *lookups, void *stream);
+/* RaceCar.update_pose without the scan (base_classes.py:254-402), n cars in place. */
+int f110_update_pose(f110_handle *h, double *state, double *steer_buf, int32_t *steer_cnt,
+                     const double *actions, int32_t n, void *stream);
+/* get_vertices (collision_models.py:238-260): [n,3] -> [n,4,2] */
+int f110_get_vertices(f110_handle *h, const double *poses, int32_t n, double *verts, void *stream);
+/* collision (GJK, collision_models.py:114-182) on n quad pairs -> hit[n] */
+int f110_gjk_pairs(f110_handle *h, const double *verts_a, const double *verts_b, int32_t n,
+                   uint8_t *hit, void *stream);
+/* collision_multiple (collision_models.py:185-212): n groups of A quads [n,A,4,2] */
+int f110_collision_multiple(f110_handle *h, const double *verts, int32_t n, int32_t A,
+                            uint8_t *collisions, int32_t *collision_idx, void *stream);
+/* check_ttc_jit (laser_models.py:189-217): scans [n,num_beams], vel [n] -> hit[n] */
+int f110_check_ttc(f110_handle *h, const double *scans, const double *vel, int32_t n, uint8_t *hit,
+                   void *stream);
+/* ray_cast (laser_models.py:319-346): scans [n,num_beams] modified in place by one
+ * opponent quad each; span [n,2] = get_blocked_view_indices (may be NULL). */
+int f110_ray_cast(f110_handle *h, const double *ego_poses, const double *opp_verts, int32_t n,
+                  double *scans, int32_t *span, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* F110_HIP_H */

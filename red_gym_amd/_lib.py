@@ -1,0 +1,102 @@
+"""ctypes binding of include/f110_hip.h (libf110_hip.so, built by red_gym_amd.build).
+
+There is no CPU fallback: if the HIP library is missing or fails to load the
+import raises, and every entry point returning a negative code raises here.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libf110_hip.so')
+
+F110_MAX_AGENTS = 8
+F110_NUM_PARAMS = 18
+F110_RK4, F110_EULER = 1, 2
+E_INVALID, E_HIP, E_NOMAP, E_INDEX, E_UNBOUND = -1, -2, -3, -4, -5
+
+PARAM_KEYS = ['mu', 'C_Sf', 'C_Sr', 'lf', 'lr', 'h', 'm', 'I', 's_min', 's_max', 'sv_min', 'sv_max',
+              'v_switch', 'a_max', 'v_min', 'v_max', 'width', 'length']
+
+
+class Config(C.Structure):
+    _fields_ = [('num_envs', C.c_int32), ('num_agents', C.c_int32), ('num_beams', C.c_int32),
+                ('theta_dis', C.c_int32), ('integrator', C.c_int32), ('ego_idx', C.c_int32),
+                ('device', C.c_int32), ('autoreset', C.c_int32), ('fov', C.c_double), ('eps', C.c_double),
+                ('max_range', C.c_double), ('timestep', C.c_double), ('ttc_thresh', C.c_double),
+                ('params', C.c_double * F110_NUM_PARAMS)]
+
+
+BUFFER_FIELDS = ['state', 'steer_buf', 'steer_cnt', 'noise_step', 'spawn', 'start_rot', 'near_start',
+                 'toggles', 'current_time', 'pending_reset', 'scans', 'scans_f64', 'pose_snap',
+                 'collisions', 'collision_idx', 'in_collision', 'lap_counts', 'lap_times', 'done', 'lookups']
+
+
+class Buffers(C.Structure):
+    _fields_ = [(name, C.c_void_p) for name in BUFFER_FIELDS]
+
+
+# every symbol include/f110_hip.h declares: name -> argtypes (restype int unless noted)
+_VP, _I32, _I64, _D = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+SYMBOLS = {
+    'f110_create': [C.POINTER(Config), C.POINTER(_VP)],
+    'f110_destroy': [_VP],
+    'f110_last_error': [],
+    'f110_update_params': [_VP, _VP],
+    'f110_set_tables': [_VP, _VP, _VP, _VP, _VP, _VP],
+    'f110_set_map_occupancy': [_VP, _VP, _I32, _I32, _D, _D, _D, _D, _D],
+    'f110_set_map_dt': [_VP, _VP, _I32, _I32, _D, _D, _D, _D, _D],
+    'f110_get_map_dt': [_VP, _VP],
+    'f110_edt_squared': [_VP, _I32, _I32, _VP],
+    'f110_set_noise_table': [_VP, _VP, _I64],
+    'f110_bind': [_VP, C.POINTER(Buffers)],
+    'f110_reset': [_VP, _VP, _VP, _VP],
+    'f110_step': [_VP, _VP, _VP],
+    'f110_scan': [_VP, _VP, _I32, _VP, _VP, _VP, _VP],
+    'f110_update_pose': [_VP, _VP, _VP, _VP, _VP, _I32, _VP],
+    'f110_get_vertices': [_VP, _VP, _I32, _VP, _VP],
+    'f110_gjk_pairs': [_VP, _VP, _VP, _I32, _VP, _VP],
+    'f110_collision_multiple': [_VP, _VP, _I32, _I32, _VP, _VP, _VP],
+    'f110_check_ttc': [_VP, _VP, _VP, _I32, _VP, _VP],
+    'f110_ray_cast': [_VP, _VP, _VP, _I32, _VP, _VP, _VP],
+}
+
+
+class F110Error(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__('f110 error %d: %s' % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Loads libf110_hip.so; raises if it is absent (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError('%s not found: build it with `python -m red_gym_amd.build` '
+                          '(hipcc --offload-arch=gfx950); there is no CPU fallback.' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    lib.f110_last_error.restype = C.c_char_p
+    lib.f110_destroy.restype = None
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    """Maps C error codes to the exceptions the reference raises for the same
+    conditions (ValueError base_classes.py:619 / laser_models.py:446, IndexError :527)."""
+    if rc == 0:
+        return
+    msg = load().f110_last_error().decode('utf-8', 'replace')
+    if rc in (E_INVALID, E_NOMAP):
+        raise ValueError(msg)
+    if rc == E_INDEX:
+        raise IndexError(msg)
+    raise F110Error(rc, msg)

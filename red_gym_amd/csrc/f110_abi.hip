@@ -1,0 +1,534 @@
+// f110_abi.hip -- C ABI (include/f110_hip.h) over the gfx950 kernels.
+// Host side: handle, map pipeline (exact EDT -> u16 cell codes + fp64 LUT),
+// table uploads, kernel launches on the caller's stream.  No allocation and no
+// synchronisation inside f110_step / f110_reset.
+#include "../../include/f110_hip.h"
+#include "f110_kernels.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+using namespace f110;
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(F110_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+struct f110_handle {
+    f110_config cfg;
+    Params params;
+    bool has_map = false, bound = false;
+    f110_buffers bufs;
+    // device tables owned by the handle
+    double *d_sines = nullptr, *d_cosines = nullptr;
+    double *d_scan_angles = nullptr, *d_beam_cosines = nullptr, *d_side = nullptr;
+    uint16_t *d_cells = nullptr;
+    double *d_lut = nullptr, *d_dt = nullptr;
+    double *d_noise = nullptr;
+    long long noise_T = 0;
+    MapDev map;
+    bool ident = false, pow2 = false;
+    double theta_inc = 0;
+};
+
+extern "C" const char *f110_last_error(void) { return g_err; }
+
+// ---------------------------------------------------------------- exact squared EDT (host)
+// Meijster, Roerdink, Hesselink (2000): two passes, integer arithmetic only, so
+// resolution*sqrt(d2) reproduces scipy.ndimage.distance_transform_edt bit for bit
+// (exact Euclidean distances; reference call site laser_models.py:52).
+extern "C" int f110_edt_squared(const uint8_t *mask, int32_t H, int32_t W, uint32_t *d2)
+{
+    if (!mask || !d2 || H <= 0 || W <= 0) return fail(F110_E_INVALID, "f110_edt_squared: bad arguments");
+    const int64_t INF = (int64_t)H + W + 1;
+    std::vector<int64_t> g((size_t)H * W);
+    bool any_zero = false;
+    for (int x = 0; x < W; x++) {
+        // distance along the column to the nearest zero cell
+        g[x] = mask[x] ? INF : 0;
+        for (int y = 1; y < H; y++) {
+            size_t i = (size_t)y * W + x;
+            g[i] = mask[i] ? (g[i - W] >= INF ? INF : g[i - W] + 1) : 0;
+        }
+        for (int y = H - 2; y >= 0; y--) {
+            size_t i = (size_t)y * W + x;
+            if (g[i + W] < g[i]) g[i] = g[i + W] + 1 < g[i] ? g[i + W] + 1 : g[i];
+        }
+    }
+    for (size_t i = 0; i < (size_t)H * W; i++)
+        if (!mask[i]) { any_zero = true; break; }
+    if (!any_zero) return fail(F110_E_INVALID, "f110_edt_squared: map has no occupied cell");
+    // columns without any occupied cell carry g = INF (> any real distance), which the
+    // lower-envelope scan handles without special cases since INF^2 exceeds every candidate
+    std::vector<int> s(W), t(W);
+    for (int y = 0; y < H; y++) {
+        const int64_t *gr = &g[(size_t)y * W];
+        auto f = [&](int64_t x, int64_t i) { return (x - i) * (x - i) + gr[i] * gr[i]; };
+        auto sep = [&](int64_t i, int64_t u) {
+            int64_t num = u * u - i * i + gr[u] * gr[u] - gr[i] * gr[i];
+            int64_t den = 2 * (u - i);
+            int64_t q = num / den;
+            if ((num % den != 0) && ((num < 0) != (den < 0))) q--; // floor division
+            return q;
+        };
+        int q = 0;
+        s[0] = 0;
+        t[0] = 0;
+        for (int u = 1; u < W; u++) {
+            while (q >= 0 && f(t[q], s[q]) > f(t[q], u)) q--;
+            if (q < 0) {
+                q = 0;
+                s[0] = u;
+            } else {
+                int64_t w = 1 + sep(s[q], u);
+                if (w < W) {
+                    q++;
+                    s[q] = u;
+                    t[q] = (int)w;
+                }
+            }
+        }
+        for (int u = W - 1; u >= 0; u--) {
+            d2[(size_t)y * W + u] = (uint32_t)f(u, s[q]);
+            if (u == t[q]) q--;
+        }
+    }
+    return F110_OK;
+}
+
+// ---------------------------------------------------------------- handle
+static void default_tables(const f110_config &c, std::vector<double> &sines, std::vector<double> &cosines,
+                           std::vector<double> &ang, std::vector<double> &bcos, std::vector<double> &side)
+{
+    // laser_models.py:379-381: np.linspace(0, 2*pi, theta_dis) (endpoint included)
+    sines.resize(c.theta_dis);
+    cosines.resize(c.theta_dis);
+    const double step = (2 * F110_PI - 0.0) / (c.theta_dis - 1);
+    for (int i = 0; i < c.theta_dis; i++) {
+        double th = i == c.theta_dis - 1 ? 2 * F110_PI : 0.0 + i * step;
+        sines[i] = std::sin(th);
+        cosines[i] = std::cos(th);
+    }
+    // base_classes.py:123-156
+    ang.resize(c.num_beams);
+    bcos.resize(c.num_beams);
+    side.resize(c.num_beams);
+    const double incr = c.fov / (c.num_beams - 1);
+    const double dist_sides = c.params[P_WIDTH] / 2.;
+    const double dist_fr = (c.params[P_LF] + c.params[P_LR]) / 2.;
+    for (int i = 0; i < c.num_beams; i++) {
+        double angle = -c.fov / 2. + i * incr;
+        double to_side, to_fr;
+        ang[i] = angle;
+        bcos[i] = std::cos(angle);
+        if (angle > 0) {
+            if (angle < F110_PI / 2) { to_side = dist_sides / std::sin(angle); to_fr = dist_fr / std::cos(angle); }
+            else { to_side = dist_sides / std::cos(angle - F110_PI / 2.); to_fr = dist_fr / std::sin(angle - F110_PI / 2.); }
+        } else {
+            if (angle > -F110_PI / 2) { to_side = dist_sides / std::sin(-angle); to_fr = dist_fr / std::cos(-angle); }
+            else { to_side = dist_sides / std::cos(-angle - F110_PI / 2); to_fr = dist_fr / std::sin(-angle - F110_PI / 2); }
+        }
+        side[i] = to_side < to_fr ? to_side : to_fr;
+    }
+}
+
+static int upload(double **dst, const double *src, size_t n)
+{
+    if (!*dst) HIP_TRY(hipMalloc((void **)dst, n * sizeof(double)));
+    HIP_TRY(hipMemcpy(*dst, src, n * sizeof(double), hipMemcpyHostToDevice));
+    return F110_OK;
+}
+
+extern "C" int f110_create(const f110_config *cfg, f110_handle **out)
+{
+    if (!cfg || !out) return fail(F110_E_INVALID, "f110_create: null argument");
+    if (cfg->num_envs < 1 || cfg->num_agents < 1 || cfg->num_agents > F110_MAX_AGENTS)
+        return fail(F110_E_INVALID, "f110_create: num_envs=%d num_agents=%d out of range (agents 1..%d)",
+                    cfg->num_envs, cfg->num_agents, F110_MAX_AGENTS);
+    if (cfg->num_beams < 2 || cfg->num_beams > 2048 || cfg->theta_dis < 2)
+        return fail(F110_E_INVALID, "f110_create: num_beams=%d (2..2048) theta_dis=%d", cfg->num_beams, cfg->theta_dis);
+    if (cfg->integrator != F110_RK4 && cfg->integrator != F110_EULER)
+        return fail(F110_E_INVALID, "f110_create: invalid integrator %d (RK4=1, Euler=2)", cfg->integrator);
+    if (cfg->ego_idx < 0 || cfg->ego_idx >= cfg->num_agents)
+        return fail(F110_E_INDEX, "f110_create: ego_idx %d out of range", cfg->ego_idx);
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (cfg->device < 0 || cfg->device >= ndev)
+        return fail(F110_E_HIP, "f110_create: device %d not available (%d HIP devices)", cfg->device, ndev);
+    HIP_TRY(hipSetDevice(cfg->device));
+    f110_handle *h = new (std::nothrow) f110_handle();
+    if (!h) return fail(F110_E_INVALID, "f110_create: out of host memory");
+    h->cfg = *cfg;
+    memcpy(h->params.v, cfg->params, sizeof(double) * P_COUNT);
+    memset(&h->bufs, 0, sizeof(h->bufs));
+    memset(&h->map, 0, sizeof(h->map));
+    // laser_models.py:367-368
+    const double angle_increment = cfg->fov / (cfg->num_beams - 1);
+    h->theta_inc = cfg->theta_dis * angle_increment / (2. * F110_PI);
+    std::vector<double> s, c, ang, bcos, side;
+    default_tables(*cfg, s, c, ang, bcos, side);
+    int rc;
+    if ((rc = upload(&h->d_sines, s.data(), s.size())) || (rc = upload(&h->d_cosines, c.data(), c.size())) ||
+        (rc = upload(&h->d_scan_angles, ang.data(), ang.size())) ||
+        (rc = upload(&h->d_beam_cosines, bcos.data(), bcos.size())) ||
+        (rc = upload(&h->d_side, side.data(), side.size()))) {
+        f110_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return F110_OK;
+}
+
+extern "C" void f110_destroy(f110_handle *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->cfg.device);
+    void *ptrs[] = {h->d_sines, h->d_cosines, h->d_scan_angles, h->d_beam_cosines, h->d_side,
+                    h->d_cells, h->d_lut, h->d_dt, h->d_noise};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    delete h;
+}
+
+extern "C" int f110_update_params(f110_handle *h, const double *p)
+{
+    if (!h || !p) return fail(F110_E_INVALID, "f110_update_params: null argument");
+    memcpy(h->params.v, p, sizeof(double) * P_COUNT);
+    memcpy(h->cfg.params, p, sizeof(double) * P_COUNT);
+    return F110_OK;
+}
+
+extern "C" int f110_set_tables(f110_handle *h, const double *sines, const double *cosines, const double *ang,
+                               const double *bcos, const double *side)
+{
+    if (!h) return fail(F110_E_INVALID, "f110_set_tables: null handle");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    int rc = F110_OK;
+    if (sines && (rc = upload(&h->d_sines, sines, h->cfg.theta_dis))) return rc;
+    if (cosines && (rc = upload(&h->d_cosines, cosines, h->cfg.theta_dis))) return rc;
+    if (ang && (rc = upload(&h->d_scan_angles, ang, h->cfg.num_beams))) return rc;
+    if (bcos && (rc = upload(&h->d_beam_cosines, bcos, h->cfg.num_beams))) return rc;
+    if (side && (rc = upload(&h->d_side, side, h->cfg.num_beams))) return rc;
+    return rc;
+}
+
+// Builds the device map from a host fp64 distance table (and, when known, its
+// exact squared form).  Cells whose value is not resolution*sqrt(integer) keep
+// the escape code and are served from the fp64 table.
+static int install_map(f110_handle *h, const double *dt, const uint32_t *d2_or_null, int H, int W, double res,
+                       double ox, double oy, double oc, double os)
+{
+    const size_t n = (size_t)H * W;
+    std::vector<uint16_t> cells(n);
+    for (size_t i = 0; i < n; i++) {
+        uint64_t d2;
+        if (d2_or_null) d2 = d2_or_null[i];
+        else {
+            double q = dt[i] / res;
+            double r = std::nearbyint(q * q);
+            d2 = (r >= 0 && r < 4.0e18) ? (uint64_t)r : (uint64_t)CODE_ESC;
+            if (d2 < (uint64_t)CODE_ESC && res * std::sqrt((double)d2) != dt[i]) d2 = CODE_ESC;
+        }
+        cells[i] = (uint16_t)(d2 < (uint64_t)CODE_ESC ? d2 : CODE_ESC);
+    }
+    std::vector<double> lut(CODE_ESC);
+    for (int i = 0; i < CODE_ESC; i++) lut[i] = res * std::sqrt((double)i);
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    HIP_TRY(hipDeviceSynchronize()); // the previous map may still be in use by enqueued steps
+    if (h->d_cells) { (void)hipFree(h->d_cells); h->d_cells = nullptr; }
+    if (h->d_dt) { (void)hipFree(h->d_dt); h->d_dt = nullptr; }
+    HIP_TRY(hipMalloc((void **)&h->d_cells, n * sizeof(uint16_t)));
+    HIP_TRY(hipMalloc((void **)&h->d_dt, n * sizeof(double)));
+    HIP_TRY(hipMemcpy(h->d_cells, cells.data(), n * sizeof(uint16_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->d_dt, dt, n * sizeof(double), hipMemcpyHostToDevice));
+    int rc = upload(&h->d_lut, lut.data(), lut.size());
+    if (rc) return rc;
+    MapDev &m = h->map;
+    m.cells = h->d_cells; m.lut = h->d_lut; m.dt = h->d_dt;
+    m.H = H; m.W = W; m.res = res; m.rinv = 1.0 / res;
+    m.ox = ox; m.oy = oy; m.oc = oc; m.os = os;
+    m.wres = W * res; // width * resolution (laser_models.py:79)
+    m.hres = H * res;
+    m.oob = dt[n - 1]; // dt[-1, -1]
+    int e = 0;
+    h->pow2 = std::frexp(res, &e) == 0.5;
+    h->ident = (oc == 1.0 && os == 0.0);
+    h->has_map = true;
+    return F110_OK;
+}
+
+static int check_map_args(f110_handle *h, const void *p, int H, int W, double res, const char *who)
+{
+    if (!h || !p) return fail(F110_E_INVALID, "%s: null argument", who);
+    if (H < 1 || W < 1 || (int64_t)H * W > (int64_t)1 << 30) return fail(F110_E_INVALID, "%s: bad map size %dx%d", who, H, W);
+    if (!(res > 0) || !std::isfinite(res)) return fail(F110_E_INVALID, "%s: bad resolution %g", who, res);
+    return F110_OK;
+}
+
+extern "C" int f110_set_map_occupancy(f110_handle *h, const uint8_t *mask, int32_t H, int32_t W, double res,
+                                      double ox, double oy, double oc, double os)
+{
+    int rc = check_map_args(h, mask, H, W, res, "f110_set_map_occupancy");
+    if (rc) return rc;
+    const size_t n = (size_t)H * W;
+    std::vector<uint32_t> d2(n);
+    if ((rc = f110_edt_squared(mask, H, W, d2.data()))) return rc;
+    std::vector<double> dt(n);
+    for (size_t i = 0; i < n; i++) dt[i] = res * std::sqrt((double)d2[i]);
+    return install_map(h, dt.data(), d2.data(), H, W, res, ox, oy, oc, os);
+}
+
+extern "C" int f110_set_map_dt(f110_handle *h, const double *dt, int32_t H, int32_t W, double res, double ox,
+                               double oy, double oc, double os)
+{
+    int rc = check_map_args(h, dt, H, W, res, "f110_set_map_dt");
+    if (rc) return rc;
+    return install_map(h, dt, nullptr, H, W, res, ox, oy, oc, os);
+}
+
+extern "C" int f110_get_map_dt(f110_handle *h, double *out)
+{
+    if (!h || !out) return fail(F110_E_INVALID, "f110_get_map_dt: null argument");
+    if (!h->has_map) return fail(F110_E_NOMAP, "Map is not set for scan simulator.");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    HIP_TRY(hipMemcpy(out, h->d_dt, (size_t)h->map.H * h->map.W * sizeof(double), hipMemcpyDeviceToHost));
+    return F110_OK;
+}
+
+extern "C" int f110_set_noise_table(f110_handle *h, const double *tbl, int64_t T)
+{
+    if (!h) return fail(F110_E_INVALID, "f110_set_noise_table: null handle");
+    if (T < 0 || (T > 0 && !tbl)) return fail(F110_E_INVALID, "f110_set_noise_table: bad table");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    HIP_TRY(hipDeviceSynchronize());
+    if (h->d_noise) { (void)hipFree(h->d_noise); h->d_noise = nullptr; }
+    h->noise_T = 0;
+    if (T == 0) return F110_OK;
+    const size_t n = (size_t)T * h->cfg.num_beams;
+    HIP_TRY(hipMalloc((void **)&h->d_noise, n * sizeof(double)));
+    HIP_TRY(hipMemcpy(h->d_noise, tbl, n * sizeof(double), hipMemcpyHostToDevice));
+    h->noise_T = T;
+    return F110_OK;
+}
+
+extern "C" int f110_bind(f110_handle *h, const f110_buffers *b)
+{
+    if (!h || !b) return fail(F110_E_INVALID, "f110_bind: null argument");
+    const void *req[] = {b->state, b->steer_buf, b->steer_cnt, b->noise_step, b->spawn, b->start_rot,
+                         b->near_start, b->toggles, b->current_time, b->pending_reset, b->scans,
+                         b->pose_snap, b->collisions, b->collision_idx, b->in_collision, b->lap_counts,
+                         b->lap_times, b->done};
+    for (const void *p : req)
+        if (!p) return fail(F110_E_INVALID, "f110_bind: a required buffer is NULL (only scans_f64 and lookups are optional)");
+    h->bufs = *b;
+    h->bound = true;
+    return F110_OK;
+}
+
+// ---------------------------------------------------------------- launches
+static ScanDev scan_dev(const f110_handle *h)
+{
+    ScanDev s;
+    s.nb = h->cfg.num_beams; s.theta_dis = h->cfg.theta_dis; s.fov = h->cfg.fov; s.eps = h->cfg.eps;
+    s.max_range = h->cfg.max_range; s.inc = h->theta_inc; s.sines = h->d_sines; s.cosines = h->d_cosines;
+    return s;
+}
+
+static int launch_scan(f110_handle *h, const ScanArgs &a, hipStream_t st)
+{
+    const int nb_pad = (a.scan.nb + 1) & ~1;
+    const size_t smem = (size_t)(LUT_LDS + SCAN_WAVES * nb_pad) * sizeof(double);
+    const dim3 grid((a.n_cars + SCAN_WAVES - 1) / SCAN_WAVES), block(SCAN_THREADS);
+    if (smem > 64 * 1024) {
+        // opt in to > 64 KiB of dynamic LDS (one workgroup may use up to 160 KiB on gfx950)
+        HIP_TRY(hipFuncSetAttribute((const void *)scan_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        HIP_TRY(hipFuncSetAttribute((const void *)scan_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        HIP_TRY(hipFuncSetAttribute((const void *)scan_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        HIP_TRY(hipFuncSetAttribute((const void *)scan_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    }
+    if (h->ident && h->pow2) hipLaunchKernelGGL((scan_kernel<true, true>), grid, block, smem, st, a);
+    else if (h->ident) hipLaunchKernelGGL((scan_kernel<true, false>), grid, block, smem, st, a);
+    else if (h->pow2) hipLaunchKernelGGL((scan_kernel<false, true>), grid, block, smem, st, a);
+    else hipLaunchKernelGGL((scan_kernel<false, false>), grid, block, smem, st, a);
+    HIP_TRY(hipGetLastError());
+    return F110_OK;
+}
+
+static int run_step(f110_handle *h, const double *actions, int reset_only, hipStream_t st)
+{
+    const f110_config &c = h->cfg;
+    const f110_buffers &b = h->bufs;
+    const int N = c.num_envs * c.num_agents;
+    DynArgs d;
+    d.n_cars = N; d.agents = c.num_agents; d.state = b.state; d.steer_buf = b.steer_buf; d.steer_cnt = b.steer_cnt;
+    d.noise_step = b.noise_step; d.actions = actions; d.spawn = b.spawn; d.pending_reset = b.pending_reset;
+    d.reset_only = reset_only; d.pose_snap = b.pose_snap; d.params = h->params; d.time_step = c.timestep;
+    d.integrator = c.integrator;
+    hipLaunchKernelGGL(dynamics_kernel, dim3((N + 255) / 256), dim3(256), 0, st, d);
+    HIP_TRY(hipGetLastError());
+
+    ScanArgs s;
+    memset(&s, 0, sizeof(s));
+    s.map = h->map; s.scan = scan_dev(h); s.n_cars = N; s.agents = c.num_agents;
+    s.pose_src = b.state; s.pose_stride = 7; s.yaw_off = 4;
+    s.state = b.state; s.pose_snap = b.pose_snap; s.noise_step = b.noise_step;
+    s.noise = h->noise_T > 0 ? h->d_noise : nullptr; s.noise_T = h->noise_T > 0 ? h->noise_T : 1;
+    s.scan_angles = h->d_scan_angles; s.beam_cosines = h->d_beam_cosines; s.side_distances = h->d_side;
+    s.ttc_thresh = c.ttc_thresh; s.car_length = h->params.v[P_LENGTH]; s.car_width = h->params.v[P_WIDTH];
+    s.in_collision = b.in_collision; s.pending_reset = b.pending_reset; s.reset_only = reset_only;
+    s.out_f32 = b.scans; s.out_f64 = b.scans_f64; s.lookups = b.lookups;
+    int rc = launch_scan(h, s, st);
+    if (rc) return rc;
+
+    EnvArgs e;
+    e.n_envs = c.num_envs; e.agents = c.num_agents; e.ego_idx = c.ego_idx; e.autoreset = c.autoreset;
+    e.reset_only = reset_only; e.state = b.state; e.pose_snap = b.pose_snap; e.spawn = b.spawn;
+    e.in_collision = b.in_collision; e.collisions = b.collisions; e.collision_idx = b.collision_idx;
+    e.start_rot = b.start_rot; e.near_start = b.near_start; e.toggles = b.toggles; e.lap_counts = b.lap_counts;
+    e.lap_times = b.lap_times; e.current_time = b.current_time; e.pending_reset = b.pending_reset; e.done = b.done;
+    e.time_step = c.timestep; e.car_length = h->params.v[P_LENGTH]; e.car_width = h->params.v[P_WIDTH];
+    hipLaunchKernelGGL(env_kernel, dim3((c.num_envs + 127) / 128), dim3(128), 0, st, e);
+    HIP_TRY(hipGetLastError());
+    return F110_OK;
+}
+
+static int check_ready(f110_handle *h, const char *who)
+{
+    if (!h) return fail(F110_E_INVALID, "%s: null handle", who);
+    if (!h->has_map) return fail(F110_E_NOMAP, "Map is not set for scan simulator.");
+    if (!h->bound) return fail(F110_E_UNBOUND, "%s: f110_bind has not been called", who);
+    return F110_OK;
+}
+
+__global__ void arm_reset_kernel(const double *poses, const uint8_t *mask, int n_envs, int agents, double *spawn,
+                                 uint8_t *pending)
+{
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= n_envs) return;
+    if (mask && !mask[env]) return;
+    for (int i = 0; i < agents * 3; i++) spawn[(size_t)env * agents * 3 + i] = poses[(size_t)env * agents * 3 + i];
+    pending[env] = 1;
+}
+
+extern "C" int f110_reset(f110_handle *h, const double *poses, const uint8_t *mask, void *stream)
+{
+    int rc = check_ready(h, "f110_reset");
+    if (rc) return rc;
+    if (!poses) return fail(F110_E_INVALID, "Number of poses for reset does not match number of agents.");
+    hipStream_t st = (hipStream_t)stream;
+    const f110_config &c = h->cfg;
+    hipLaunchKernelGGL(arm_reset_kernel, dim3((c.num_envs + 255) / 256), dim3(256), 0, st, poses, mask, c.num_envs,
+                       c.num_agents, h->bufs.spawn, h->bufs.pending_reset);
+    HIP_TRY(hipGetLastError());
+    // the zero-action step of F110Env.reset; actions are not read for pending envs
+    return run_step(h, nullptr, 1, st);
+}
+
+extern "C" int f110_step(f110_handle *h, const double *actions, void *stream)
+{
+    int rc = check_ready(h, "f110_step");
+    if (rc) return rc;
+    if (!actions) return fail(F110_E_INVALID, "f110_step: null actions");
+    return run_step(h, actions, 0, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------- function-level entry points
+extern "C" int f110_scan(f110_handle *h, const double *poses, int32_t n, double *out64, float *out32,
+                         uint32_t *lookups, void *stream)
+{
+    if (!h || n < 0) return fail(F110_E_INVALID, "f110_scan: bad arguments");
+    if (!h->has_map) return fail(F110_E_NOMAP, "Map is not set for scan simulator.");
+    if (n == 0) return F110_OK;
+    if (!poses || (!out64 && !out32)) return fail(F110_E_INVALID, "f110_scan: null pose or output pointer");
+    ScanArgs s;
+    memset(&s, 0, sizeof(s));
+    s.map = h->map; s.scan = scan_dev(h); s.n_cars = n; s.agents = 1;
+    s.pose_src = poses; s.pose_stride = 3; s.yaw_off = 2;
+    s.out_f32 = out32; s.out_f64 = out64; s.lookups = lookups; s.noise_T = 1;
+    return launch_scan(h, s, (hipStream_t)stream);
+}
+
+extern "C" int f110_update_pose(f110_handle *h, double *state, double *steer_buf, int32_t *steer_cnt,
+                                const double *actions, int32_t n, void *stream)
+{
+    if (h && n == 0) return F110_OK;
+    if (!h || !state || !steer_buf || !steer_cnt || !actions || n < 0)
+        return fail(F110_E_INVALID, "f110_update_pose: bad arguments");
+    DynArgs d;
+    memset(&d, 0, sizeof(d));
+    d.n_cars = n; d.agents = 1; d.state = state; d.steer_buf = steer_buf; d.steer_cnt = steer_cnt; d.actions = actions;
+    d.params = h->params; d.time_step = h->cfg.timestep; d.integrator = h->cfg.integrator;
+    hipLaunchKernelGGL(dynamics_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, d);
+    HIP_TRY(hipGetLastError());
+    return F110_OK;
+}
+
+extern "C" int f110_get_vertices(f110_handle *h, const double *poses, int32_t n, double *verts, void *stream)
+{
+    if (h && n == 0) return F110_OK;
+    if (!h || !poses || !verts || n < 0) return fail(F110_E_INVALID, "f110_get_vertices: bad arguments");
+    hipLaunchKernelGGL(vertices_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, poses, n,
+                       h->params.v[P_LENGTH], h->params.v[P_WIDTH], verts);
+    HIP_TRY(hipGetLastError());
+    return F110_OK;
+}
+
+extern "C" int f110_gjk_pairs(f110_handle *h, const double *va, const double *vb, int32_t n, uint8_t *hit, void *stream)
+{
+    if (h && n == 0) return F110_OK;
+    if (!h || !va || !vb || !hit || n < 0) return fail(F110_E_INVALID, "f110_gjk_pairs: bad arguments");
+    hipLaunchKernelGGL(gjk_pairs_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, va, vb, n, hit);
+    HIP_TRY(hipGetLastError());
+    return F110_OK;
+}
+
+extern "C" int f110_collision_multiple(f110_handle *h, const double *verts, int32_t n, int32_t A, uint8_t *col,
+                                       int32_t *cidx, void *stream)
+{
+    if (h && n == 0) return F110_OK;
+    if (!h || !verts || !col || !cidx || n < 0 || A < 1) return fail(F110_E_INVALID, "f110_collision_multiple: bad arguments");
+    hipLaunchKernelGGL(collision_multiple_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, verts, n, A,
+                       col, cidx);
+    HIP_TRY(hipGetLastError());
+    return F110_OK;
+}
+
+extern "C" int f110_check_ttc(f110_handle *h, const double *scans, const double *vel, int32_t n, uint8_t *hit,
+                              void *stream)
+{
+    if (h && n == 0) return F110_OK;
+    if (!h || !scans || !vel || !hit || n < 0) return fail(F110_E_INVALID, "f110_check_ttc: bad arguments");
+    hipLaunchKernelGGL(ttc_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, scans, vel, n, h->cfg.num_beams,
+                       h->d_beam_cosines, h->d_side, h->cfg.ttc_thresh, hit);
+    HIP_TRY(hipGetLastError());
+    return F110_OK;
+}
+
+extern "C" int f110_ray_cast(f110_handle *h, const double *ego, const double *verts, int32_t n, double *scans,
+                             int32_t *span, void *stream)
+{
+    if (h && n == 0) return F110_OK;
+    if (!h || !ego || !verts || !scans || n < 0) return fail(F110_E_INVALID, "f110_ray_cast: bad arguments");
+    hipLaunchKernelGGL(ray_cast_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, ego, verts, n,
+                       h->cfg.num_beams, h->d_scan_angles, scans, span);
+    HIP_TRY(hipGetLastError());
+    return F110_OK;
+}

@@ -1,0 +1,481 @@
+// f110_kernels.h -- the three kernels of one batched env step on gfx950:
+//   dynamics_kernel  (lane per car)   RaceCar.update_pose minus the scan
+//   scan_kernel      (wave per car)   ScanSimulator2D.scan + noise + iTTC + opponent ray cast
+//   env_kernel       (lane per env)   GJK, collision flags, lap timing, done, autoreset
+// plus small function-level kernels used by the parity entry points.
+#pragma once
+#include "f110_device.h"
+
+#pragma clang fp contract(off)
+
+namespace f110 {
+
+constexpr int WAVE = 64;
+constexpr int SCAN_WAVES = 8;                 // cars per workgroup (one wavefront each)
+constexpr int SCAN_THREADS = SCAN_WAVES * WAVE;
+constexpr int LUT_LDS = 1024;                 // distance LUT entries staged in LDS (d2 < 1024)
+constexpr int CODE_ESC = 65535;               // cell code: read the fp64 table instead
+constexpr int REFILL_MIN_IDLE = 16;           // refill the wave's beam slots once this many lanes idle
+
+struct MapDev {
+    const uint16_t *cells;  // [H*W] min(d2, 65535); 65535 = escape to dt
+    const double *lut;      // [65535] resolution*sqrt(d2)
+    const double *dt;       // [H*W] exact fp64 distance table (escape path, rarely touched)
+    int H, W;
+    double res, rinv, ox, oy, oc, os, wres, hres, oob; // oob = dt[H-1][W-1] (laser_models.py:80-81,103)
+};
+
+struct ScanDev {
+    int nb, theta_dis;
+    double fov, eps, max_range, inc; // inc = theta_index_increment (laser_models.py:368)
+    const double *sines, *cosines;   // [theta_dis] (laser_models.py:379-381)
+};
+
+// laser_models.py:56-104: (x, y) -> distance-table value.  IDENT: origin yaw == 0
+// (c=1, s=0: the rotation is the identity in exact arithmetic).  POW2: resolution
+// is a power of two, so multiplying by 1/res equals the reference's division.
+template <bool IDENT, bool POW2>
+__device__ inline double dist_lookup(const MapDev &m, const double *lds_lut, double x, double y)
+{
+    double xt = x - m.ox, yt = y - m.oy;
+    double xr, yr;
+    if (IDENT) { xr = xt; yr = yt; }
+    else { xr = xt * m.oc + yt * m.os; yr = -xt * m.os + yt * m.oc; }
+    // negated >= also sends NaN to the out-of-bounds value instead of a wild index
+    bool oob = !(xr >= 0) || (xr >= m.wres) || !(yr >= 0) || (yr >= m.hres);
+    double qx = xr * m.rinv, qy = yr * m.rinv;
+    int ci = (int)qx, ri = (int)qy;
+    if (!POW2) {
+        // int(x_rot/resolution) needs the IEEE quotient: q*rinv is within ~2e-12 of it,
+        // so only quotients within 1e-9 of an integer take the true division.
+        double fx = qx - (double)ci, fy = qy - (double)ri;
+        if (fx < 1e-9 || fx > 1. - 1e-9) ci = (int)(xr / m.res);
+        if (fy < 1e-9 || fy > 1. - 1e-9) ri = (int)(yr / m.res);
+    }
+    ci = ci < 0 ? 0 : (ci > m.W - 1 ? m.W - 1 : ci);
+    ri = ri < 0 ? 0 : (ri > m.H - 1 ? m.H - 1 : ri);
+    int idx = oob ? 0 : ri * m.W + ci;
+    unsigned code = m.cells[idx];
+    double d;
+    if (code < (unsigned)LUT_LDS) d = lds_lut[code];
+    else if (code != (unsigned)CODE_ESC) d = m.lut[code];
+    else d = m.dt[idx];
+    return oob ? m.oob : d;
+}
+
+// laser_models.py:167-184: LUT index of beam b.  The reference advances
+// theta_index by 1080 sequential fp64 adds; t0w + b*inc differs from that by
+// < 3e-10, so the truncation agrees unless the value is within 1e-8 of an
+// integer -- then this lane replays the recurrence exactly.
+__device__ inline int beam_theta_index(double t0w, int b, const ScanDev &s)
+{
+    const double td = (double)s.theta_dis;
+    double t = t0w + (double)b * s.inc;
+    t -= floor(t / td) * td;
+    int idx = (int)t;
+    double fr = t - (double)idx;
+    if (!(fr > 1e-8 && fr < 1. - 1e-8) || idx < 0 || idx >= s.theta_dis) {
+        double tt = t0w;
+        for (int j = 0; j < b; j++) {
+            tt += s.inc;
+            while (tt >= td) tt -= td;
+        }
+        idx = (int)tt;
+    }
+    return idx;
+}
+
+struct ScanArgs {
+    MapDev map;
+    ScanDev scan;
+    int n_cars;
+    int agents;             // A (cars of one env are consecutive)
+    // pose source: pose = (src[car*stride], src[car*stride+1], src[car*stride+yaw_off])
+    const double *pose_src;
+    int pose_stride, yaw_off;
+    // full-step extras (all NULL for the function-level scan)
+    double *state;               // [N,7]: read vel, zero state[3:] on iTTC hit
+    const double *pose_snap;     // [N,3]: opponents' poses
+    int32_t *noise_step;         // [N]
+    const double *noise;         // [T,nb] or NULL
+    long long noise_T;
+    const double *scan_angles, *beam_cosines, *side_distances; // [nb]
+    double ttc_thresh, car_length, car_width;
+    uint8_t *in_collision;       // [N]
+    const uint8_t *pending_reset;// [B]
+    int reset_only;              // 1: only envs with pending_reset are processed
+    // outputs
+    float *out_f32;              // [N,nb] or NULL
+    double *out_f64;             // [N,nb] or NULL
+    uint32_t *lookups;           // [N] or NULL
+};
+
+template <bool IDENT, bool POW2>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *s_lut = reinterpret_cast<double *>(smem);
+    const int nb = a.scan.nb;
+    const int nb_pad = (nb + 1) & ~1;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double *s_res = s_lut + LUT_LDS + wave * nb_pad;
+
+    for (int i = threadIdx.x; i < LUT_LDS; i += SCAN_THREADS) s_lut[i] = a.map.lut[i];
+    __syncthreads();
+
+    const int car = blockIdx.x * SCAN_WAVES + wave;
+    if (car >= a.n_cars) return;
+    const int env = car / a.agents;
+    if (a.reset_only && !a.pending_reset[env]) return;
+
+    const double px = a.pose_src[(size_t)car * a.pose_stride];
+    const double py = a.pose_src[(size_t)car * a.pose_stride + 1];
+    const double yaw = a.pose_src[(size_t)car * a.pose_stride + a.yaw_off];
+    const double eps = a.scan.eps, max_range = a.scan.max_range;
+
+    // ---- ray march (laser_models.py:107-186) -------------------------------------
+    // The first table read of every beam is at the car itself (:129): done once.
+    const double d0 = dist_lookup<IDENT, POW2>(a.map, s_lut, px, py);
+    unsigned nlook = 0;
+    if (!(d0 > eps && d0 <= max_range)) {
+        const double v = d0 > max_range ? max_range : d0;
+        for (int i = lane; i < nb; i += WAVE) s_res[i] = v;
+    } else {
+        const double td = (double)a.scan.theta_dis;
+        double t0w = td * (yaw - a.scan.fov / 2.) / (2. * F110_PI);
+        t0w = fmod(t0w, td);
+        while (t0w < 0) t0w += td;
+
+        int next = 0;           // wave-uniform: next unassigned beam
+        bool active = false;
+        int beam = 0;
+        double x = 0, y = 0, c = 0, s = 0, total = 0;
+        while (true) {
+            const unsigned long long idle = __ballot(!active);
+            const int nidle = __popcll(idle);
+            if (next < nb && (nidle >= REFILL_MIN_IDLE || nidle == WAVE)) {
+                if (!active) {
+                    const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32),
+                                        __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
+                    const int b = next + rank;
+                    if (b < nb) {
+                        const int ti = beam_theta_index(t0w, b, a.scan);
+                        s = a.scan.sines[ti];
+                        c = a.scan.cosines[ti];
+                        x = px + d0 * c;
+                        y = py + d0 * s;
+                        total = d0;
+                        beam = b;
+                        active = true;
+                    }
+                }
+                next += nidle;
+            } else if (nidle == WAVE) {
+                break;
+            }
+            if (active) {
+                const double d = dist_lookup<IDENT, POW2>(a.map, s_lut, x, y);
+                nlook++;
+                total += d;
+                if (d > eps && total <= max_range) {
+                    x += d * c;
+                    y += d * s;
+                } else {
+                    s_res[beam] = total > max_range ? max_range : total;
+                    active = false;
+                }
+            }
+        }
+    }
+    if (a.lookups) {
+        // the reference reads the table once per beam before marching
+        unsigned tot = nlook;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
+        if (lane == 0) a.lookups[car] = tot + (unsigned)nb;
+    }
+
+    // ---- noise + iTTC (laser_models.py:450-452, :189-217; base_classes.py:227-252) ----
+    double ryaw = yaw;
+    if (a.state) {
+        double *st = a.state + (size_t)car * 7;
+        const double vel = st[3];
+        const double *nz = nullptr;
+        if (a.noise) {
+            const long long row = (long long)a.noise_step[car] % a.noise_T;
+            nz = a.noise + (size_t)row * nb;
+        }
+        bool hit = false;
+        for (int i = lane; i < nb; i += WAVE) {
+            double v = s_res[i];
+            if (nz) v += nz[i];
+            if (vel != 0.0) {
+                const double proj_vel = vel * a.beam_cosines[i];
+                const double ttc = (v - a.side_distances[i]) / proj_vel;
+                if ((ttc < a.ttc_thresh) && (ttc >= 0.0)) hit = true;
+            }
+            s_res[i] = v;
+        }
+        const bool any_hit = __ballot(hit) != 0ull;
+        if (lane == 0) {
+            if (any_hit) { st[3] = 0.; st[4] = 0.; st[5] = 0.; st[6] = 0.; }
+            a.in_collision[car] = any_hit ? 1 : 0;
+            a.noise_step[car] += 1;
+        }
+        if (any_hit) ryaw = 0.;
+        // ---- opponents (base_classes.py:204-225): own current pose vs snapshot poses ----
+        if (a.agents > 1) {
+            const int a0 = env * a.agents;
+            for (int j = 0; j < a.agents; j++) {
+                if (a0 + j == car) continue;
+                const double *op = a.pose_snap + (size_t)(a0 + j) * 3;
+                double verts[4][2];
+                get_vertices(op[0], op[1], op[2], a.car_length, a.car_width, verts);
+                ray_cast_wave(px, py, ryaw, verts, a.scan_angles, nb, lane, s_res, nullptr);
+            }
+        }
+    }
+
+    // ---- coalesced write-out -------------------------------------------------------
+    if (a.out_f32) {
+        float *o = a.out_f32 + (size_t)car * nb;
+        for (int i = lane; i < nb; i += WAVE) o[i] = (float)s_res[i];
+    }
+    if (a.out_f64) {
+        double *o = a.out_f64 + (size_t)car * nb;
+        for (int i = lane; i < nb; i += WAVE) o[i] = s_res[i];
+    }
+}
+
+// ------------------------------------------------------------------ dynamics (lane per car)
+struct DynArgs {
+    int n_cars, agents;
+    double *state;        // [N,7]
+    double *steer_buf;    // [N,2]
+    int32_t *steer_cnt;   // [N]
+    int32_t *noise_step;  // [N] or NULL
+    const double *actions;// [N,2] (steer, speed)
+    const double *spawn;  // [N,3] or NULL
+    const uint8_t *pending_reset; // [B] or NULL
+    int reset_only;
+    double *pose_snap;    // [N,3] or NULL
+    Params params;
+    double time_step;
+    int integrator;
+};
+
+__global__ __launch_bounds__(256) void dynamics_kernel(DynArgs a)
+{
+    const int car = blockIdx.x * blockDim.x + threadIdx.x;
+    if (car >= a.n_cars) return;
+    const int env = car / a.agents;
+    const bool pend = a.pending_reset && a.pending_reset[env];
+    if (a.reset_only && !pend) return;
+    double st[7], sb[2];
+    int sc;
+    double steer, speed;
+    if (pend) {
+        // RaceCar.reset (base_classes.py:181-202) followed by the zero-action step of
+        // F110Env.reset (f110_env.py:335-336)
+#pragma unroll
+        for (int i = 0; i < 7; i++) st[i] = 0.;
+        st[0] = a.spawn[(size_t)car * 3];
+        st[1] = a.spawn[(size_t)car * 3 + 1];
+        st[4] = a.spawn[(size_t)car * 3 + 2];
+        sb[0] = sb[1] = 0.;
+        sc = 0;
+        steer = 0.;
+        speed = 0.;
+        if (a.noise_step) a.noise_step[car] = 0;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 7; i++) st[i] = a.state[(size_t)car * 7 + i];
+        sb[0] = a.steer_buf[(size_t)car * 2];
+        sb[1] = a.steer_buf[(size_t)car * 2 + 1];
+        sc = a.steer_cnt[car];
+        steer = a.actions[(size_t)car * 2];
+        speed = a.actions[(size_t)car * 2 + 1];
+    }
+    update_pose(st, sb, sc, steer, speed, a.params, a.time_step, a.integrator);
+#pragma unroll
+    for (int i = 0; i < 7; i++) a.state[(size_t)car * 7 + i] = st[i];
+    a.steer_buf[(size_t)car * 2] = sb[0];
+    a.steer_buf[(size_t)car * 2 + 1] = sb[1];
+    a.steer_cnt[car] = sc;
+    if (a.pose_snap) {
+        a.pose_snap[(size_t)car * 3] = st[0];
+        a.pose_snap[(size_t)car * 3 + 1] = st[1];
+        a.pose_snap[(size_t)car * 3 + 2] = st[4];
+    }
+}
+
+// ------------------------------------------------------------------ env bookkeeping (lane per env)
+struct EnvArgs {
+    int n_envs, agents, ego_idx, autoreset, reset_only;
+    const double *state;      // [N,7] (after iTTC zeroing)
+    const double *pose_snap;  // [N,3]
+    const double *spawn;      // [N,3]
+    const uint8_t *in_collision; // [N]
+    uint8_t *collisions;      // [N]
+    int32_t *collision_idx;   // [N]
+    double *start_rot;        // [B,4]
+    uint8_t *near_start;      // [N]
+    int32_t *toggles;         // [N]
+    int32_t *lap_counts;      // [N]
+    double *lap_times;        // [N]
+    double *current_time;     // [B]
+    uint8_t *pending_reset;   // [B]
+    uint8_t *done;            // [B]
+    double time_step, car_length, car_width;
+};
+
+// collision_models.py:185-212 on A <= 8 quads held in registers/scratch
+__device__ inline void collision_multiple_dev(const double *poses /*[A,3]*/, int A, double L, double W,
+                                              uint8_t *col, int32_t *cidx)
+{
+    for (int i = 0; i < A; i++) { col[i] = 0; cidx[i] = -1; }
+    for (int i = 0; i < A - 1; i++) {
+        double vi[4][2];
+        get_vertices(poses[3 * i], poses[3 * i + 1], poses[3 * i + 2], L, W, vi);
+        for (int j = i + 1; j < A; j++) {
+            double vj[4][2];
+            get_vertices(poses[3 * j], poses[3 * j + 1], poses[3 * j + 2], L, W, vj);
+            if (gjk_collision(vi, vj)) {
+                col[i] = 1; col[j] = 1;
+                cidx[i] = j; cidx[j] = i;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(128) void env_kernel(EnvArgs a)
+{
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= a.n_envs) return;
+    const bool pend = a.pending_reset[env] != 0;
+    if (a.reset_only && !pend) return;
+    const int A = a.agents, c0 = env * A;
+    // Simulator.check_collision (base_classes.py:529-543) on the post-integration poses
+    collision_multiple_dev(a.pose_snap + (size_t)c0 * 3, A, a.car_length, a.car_width,
+                           a.collisions + c0, a.collision_idx + c0);
+    for (int i = 0; i < A; i++)
+        if (a.in_collision[c0 + i]) a.collisions[c0 + i] = 1; // :581-582
+    double ct = a.current_time[env];
+    double r00, r01, r10, r11;
+    if (pend) {
+        // F110Env.reset (f110_env.py:318-329)
+        ct = 0.0;
+        const double th = -a.spawn[(size_t)(c0 + a.ego_idx) * 3 + 2];
+        r00 = cos(th); r01 = -sin(th); r10 = sin(th); r11 = cos(th);
+        a.start_rot[(size_t)env * 4] = r00; a.start_rot[(size_t)env * 4 + 1] = r01;
+        a.start_rot[(size_t)env * 4 + 2] = r10; a.start_rot[(size_t)env * 4 + 3] = r11;
+        for (int i = 0; i < A; i++) { a.near_start[c0 + i] = 1; a.toggles[c0 + i] = 0; }
+        a.pending_reset[env] = 0;
+    } else {
+        r00 = a.start_rot[(size_t)env * 4]; r01 = a.start_rot[(size_t)env * 4 + 1];
+        r10 = a.start_rot[(size_t)env * 4 + 2]; r11 = a.start_rot[(size_t)env * 4 + 3];
+    }
+    ct = ct + a.time_step; // f110_env.py:293
+    a.current_time[env] = ct;
+    // _check_done (f110_env.py:202-244)
+    const double left_t = 2, right_t = 2;
+    bool all_done = true;
+    for (int i = 0; i < A; i++) {
+        const int car = c0 + i;
+        const double px = a.state[(size_t)car * 7] - a.spawn[(size_t)car * 3];
+        const double py = a.state[(size_t)car * 7 + 1] - a.spawn[(size_t)car * 3 + 1];
+        const double dx = r00 * px + r01 * py;
+        double temp_y = r10 * px + r11 * py;
+        if (temp_y > left_t) temp_y -= left_t;
+        else if (temp_y < -right_t) temp_y = -right_t - temp_y;
+        else temp_y = 0;
+        const double dist2 = dx * dx + temp_y * temp_y;
+        const bool closes = dist2 <= 0.1;
+        bool ns = a.near_start[car] != 0;
+        int tg = a.toggles[car];
+        if (closes && !ns) { ns = true; tg += 1; }
+        else if (!closes && ns) { ns = false; tg += 1; }
+        a.near_start[car] = ns ? 1 : 0;
+        a.toggles[car] = tg;
+        a.lap_counts[car] = tg / 2;
+        if (tg < 4) a.lap_times[car] = ct;
+        if (!(tg >= 4)) all_done = false;
+    }
+    const bool dn = (a.collisions[c0 + a.ego_idx] != 0) || all_done;
+    a.done[env] = dn ? 1 : 0;
+    if (a.autoreset && dn) a.pending_reset[env] = 1;
+}
+
+// ------------------------------------------------------------------ function-level kernels
+__global__ void vertices_kernel(const double *poses, int n, double L, double W, double *out)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double v[4][2];
+    get_vertices(poses[3 * i], poses[3 * i + 1], poses[3 * i + 2], L, W, v);
+    for (int k = 0; k < 4; k++) { out[(size_t)i * 8 + 2 * k] = v[k][0]; out[(size_t)i * 8 + 2 * k + 1] = v[k][1]; }
+}
+
+__global__ void gjk_pairs_kernel(const double *va, const double *vb, int n, uint8_t *hit)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double a[4][2], b[4][2];
+    for (int k = 0; k < 4; k++) {
+        a[k][0] = va[(size_t)i * 8 + 2 * k]; a[k][1] = va[(size_t)i * 8 + 2 * k + 1];
+        b[k][0] = vb[(size_t)i * 8 + 2 * k]; b[k][1] = vb[(size_t)i * 8 + 2 * k + 1];
+    }
+    hit[i] = gjk_collision(a, b) ? 1 : 0;
+}
+
+__global__ void collision_multiple_kernel(const double *verts, int n, int A, uint8_t *col, int32_t *cidx)
+{
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    const double *v = verts + (size_t)g * A * 8;
+    uint8_t *c = col + (size_t)g * A;
+    int32_t *x = cidx + (size_t)g * A;
+    for (int i = 0; i < A; i++) { c[i] = 0; x[i] = -1; }
+    for (int i = 0; i < A - 1; i++) {
+        double vi[4][2];
+        for (int k = 0; k < 4; k++) { vi[k][0] = v[i * 8 + 2 * k]; vi[k][1] = v[i * 8 + 2 * k + 1]; }
+        for (int j = i + 1; j < A; j++) {
+            double vj[4][2];
+            for (int k = 0; k < 4; k++) { vj[k][0] = v[j * 8 + 2 * k]; vj[k][1] = v[j * 8 + 2 * k + 1]; }
+            if (gjk_collision(vi, vj)) { c[i] = 1; c[j] = 1; x[i] = j; x[j] = i; }
+        }
+    }
+}
+
+// check_ttc_jit (laser_models.py:189-217): wave per scan
+__global__ void ttc_kernel(const double *scans, const double *vel, int n, int nb, const double *beam_cosines,
+                           const double *side_distances, double thresh, uint8_t *hit)
+{
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= n) return;
+    const double v = vel[row];
+    bool h = false;
+    if (v != 0.0) {
+        for (int i = lane; i < nb; i += WAVE) {
+            const double proj_vel = v * beam_cosines[i];
+            const double ttc = (scans[(size_t)row * nb + i] - side_distances[i]) / proj_vel;
+            if ((ttc < thresh) && (ttc >= 0.0)) h = true;
+        }
+    }
+    const bool any = __ballot(h) != 0ull;
+    if (lane == 0) hit[row] = any ? 1 : 0;
+}
+
+// ray_cast (laser_models.py:319-346): wave per (ego, opponent quad)
+__global__ void ray_cast_kernel(const double *ego, const double *verts, int n, int nb, const double *scan_angles,
+                                double *scans, int32_t *span)
+{
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= n) return;
+    double v[4][2];
+    for (int k = 0; k < 4; k++) { v[k][0] = verts[(size_t)row * 8 + 2 * k]; v[k][1] = verts[(size_t)row * 8 + 2 * k + 1]; }
+    ray_cast_wave(ego[3 * row], ego[3 * row + 1], ego[3 * row + 2], v, scan_angles, nb, lane,
+                  scans + (size_t)row * nb, span ? span + 2 * row : nullptr);
+}
+
+} // namespace f110

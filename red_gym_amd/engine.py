@@ -1,0 +1,307 @@
+"""Engine: owns one f110_handle (one GPU), the torch tensors bound to it and the
+host-built tables.  Thin: all compute is in libf110_hip.so."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .base_classes import integrator_code
+from .maps import load_map
+
+# f110_env.py:128
+DEFAULT_PARAMS = {'mu': 1.0489, 'C_Sf': 4.718, 'C_Sr': 5.4562, 'lf': 0.15875, 'lr': 0.17145, 'h': 0.074,
+                  'm': 3.74, 'I': 0.04712, 's_min': -0.4189, 's_max': 0.4189, 'sv_min': -3.2, 'sv_max': 3.2,
+                  'v_switch': 7.319, 'a_max': 9.51, 'v_min': -5.0, 'v_max': 20.0, 'width': 0.31, 'length': 0.58}
+
+_TORCH_DTYPES = {
+    'state': torch.float64, 'steer_buf': torch.float64, 'steer_cnt': torch.int32, 'noise_step': torch.int32,
+    'spawn': torch.float64, 'start_rot': torch.float64, 'near_start': torch.uint8, 'toggles': torch.int32,
+    'current_time': torch.float64, 'pending_reset': torch.uint8, 'scans': torch.float32,
+    'scans_f64': torch.float64, 'pose_snap': torch.float64, 'collisions': torch.uint8,
+    'collision_idx': torch.int32, 'in_collision': torch.uint8, 'lap_counts': torch.int32,
+    'lap_times': torch.float64, 'done': torch.uint8, 'lookups': torch.int32,
+}
+
+
+def params_vec(params):
+    return np.array([float(params[k]) for k in _lib.PARAM_KEYS], dtype=np.float64)
+
+
+def beam_tables(num_beams, fov, params):
+    """RaceCar.__init__ tables (base_classes.py:120-156), computed with numpy like the reference."""
+    scan_ang_incr = fov / (num_beams - 1)
+    cosines = np.zeros((num_beams,))
+    scan_angles = np.zeros((num_beams,))
+    side_distances = np.zeros((num_beams,))
+    dist_sides = params['width'] / 2.
+    dist_fr = (params['lf'] + params['lr']) / 2.
+    for i in range(num_beams):
+        angle = -fov / 2. + i * scan_ang_incr
+        scan_angles[i] = angle
+        cosines[i] = np.cos(angle)
+        if angle > 0:
+            if angle < np.pi / 2:
+                to_side = dist_sides / np.sin(angle)
+                to_fr = dist_fr / np.cos(angle)
+            else:
+                to_side = dist_sides / np.cos(angle - np.pi / 2.)
+                to_fr = dist_fr / np.sin(angle - np.pi / 2.)
+        else:
+            if angle > -np.pi / 2:
+                to_side = dist_sides / np.sin(-angle)
+                to_fr = dist_fr / np.cos(-angle)
+            else:
+                to_side = dist_sides / np.cos(-angle - np.pi / 2)
+                to_fr = dist_fr / np.sin(-angle - np.pi / 2)
+        side_distances[i] = min(to_side, to_fr)
+    return scan_angles, cosines, side_distances
+
+
+class NoiseTable(object):
+    """Rows of `default_rng(seed).normal(0, std, num_beams)` (laser_models.py:451,
+    base_classes.py:202): every car draws one row per scan since its reset."""
+
+    def __init__(self, seed, num_beams, std_dev=0.01):
+        self.seed, self.num_beams, self.std_dev = seed, num_beams, std_dev
+        self._rng = np.random.default_rng(seed=seed)
+        self.rows = np.zeros((0, num_beams))
+
+    def ensure(self, steps):
+        if steps > self.rows.shape[0]:
+            new = [self._rng.normal(0., self.std_dev, size=self.num_beams)
+                   for _ in range(steps - self.rows.shape[0])]
+            self.rows = np.ascontiguousarray(np.concatenate([self.rows, np.stack(new)], axis=0))
+        return self.rows
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Engine(object):
+    def __init__(self, num_envs=1, num_agents=1, params=None, seed=12345, fov=2 * np.pi, timestep=0.01,
+                 integrator=1, ego_idx=0, num_beams=1080, eps=0.0001, theta_dis=2000, max_range=30.0,
+                 ttc_thresh=0.005, device=0, autoreset=False, noise_std=0.01, noise_steps=4096,
+                 keep_f64_scans=False, count_lookups=False):
+        if not torch.cuda.is_available():
+            raise RuntimeError('red_gym_amd needs a HIP device (torch.cuda.is_available() is False); '
+                               'there is no CPU path.')
+        self.lib = _lib.load()
+        self.params = dict(DEFAULT_PARAMS if params is None else params)
+        self.B, self.A, self.num_beams = int(num_envs), int(num_agents), int(num_beams)
+        self.N = self.B * self.A
+        self.fov, self.timestep, self.seed = float(fov), float(timestep), seed
+        self.device_index = int(device)
+        self.device = torch.device('cuda', self.device_index)
+        cfg = _lib.Config()
+        cfg.num_envs, cfg.num_agents, cfg.num_beams, cfg.theta_dis = self.B, self.A, self.num_beams, int(theta_dis)
+        cfg.integrator, cfg.ego_idx = integrator_code(integrator), int(ego_idx)
+        cfg.device, cfg.autoreset = self.device_index, int(bool(autoreset))
+        cfg.fov, cfg.eps, cfg.max_range = self.fov, float(eps), float(max_range)
+        cfg.timestep, cfg.ttc_thresh = self.timestep, float(ttc_thresh)
+        cfg.params[:] = list(params_vec(self.params))
+        self._h = C.c_void_p()
+        _lib.check(self.lib.f110_create(C.byref(cfg), C.byref(self._h)))
+        # tables computed with numpy exactly as the reference does (laser_models.py:379-381)
+        theta_arr = np.linspace(0.0, 2 * np.pi, num=int(theta_dis))
+        self.sines = np.ascontiguousarray(np.sin(theta_arr))
+        self.cosines = np.ascontiguousarray(np.cos(theta_arr))
+        self.scan_angles, self.beam_cosines, self.side_distances = beam_tables(self.num_beams, self.fov, self.params)
+        _lib.check(self.lib.f110_set_tables(self._h, _np_ptr(self.sines), _np_ptr(self.cosines),
+                                            _np_ptr(self.scan_angles), _np_ptr(self.beam_cosines),
+                                            _np_ptr(self.side_distances)))
+        self.map = None
+        self.noise = None
+        self._noise_dev_rows = 0
+        self.host_steps_bound = 0
+        if noise_std and noise_std > 0:
+            self.noise = NoiseTable(seed, self.num_beams, noise_std)
+            self._upload_noise(int(noise_steps))
+        self._alloc(keep_f64_scans, count_lookups)
+
+    # ------------------------------------------------------------------ buffers
+    def _alloc(self, keep_f64, count_lookups):
+        B, A, N, nb, dev = self.B, self.A, self.N, self.num_beams, self.device
+        shapes = {'state': (B, A, 7), 'steer_buf': (B, A, 2), 'steer_cnt': (B, A), 'noise_step': (B, A),
+                  'spawn': (B, A, 3), 'start_rot': (B, 4), 'near_start': (B, A), 'toggles': (B, A),
+                  'current_time': (B,), 'pending_reset': (B,), 'scans': (B, A, nb), 'scans_f64': (B, A, nb),
+                  'pose_snap': (B, A, 3), 'collisions': (B, A), 'collision_idx': (B, A), 'in_collision': (B, A),
+                  'lap_counts': (B, A), 'lap_times': (B, A), 'done': (B,), 'lookups': (B, A)}
+        self.t = {}
+        bufs = _lib.Buffers()
+        for name in _lib.BUFFER_FIELDS:
+            if (name == 'scans_f64' and not keep_f64) or (name == 'lookups' and not count_lookups):
+                self.t[name] = None
+                setattr(bufs, name, None)
+                continue
+            self.t[name] = torch.zeros(shapes[name], dtype=_TORCH_DTYPES[name], device=dev)
+            setattr(bufs, name, self.t[name].data_ptr())
+        self.t['start_rot'][:, 0] = 1.
+        self.t['start_rot'][:, 3] = 1.
+        self.t['near_start'].fill_(1)
+        self.t['collision_idx'].fill_(-1)
+        torch.cuda.synchronize(dev)
+        _lib.check(self.lib.f110_bind(self._h, C.byref(bufs)))
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _upload_noise(self, rows):
+        tbl = self.noise.ensure(rows)
+        _lib.check(self.lib.f110_set_noise_table(self._h, _np_ptr(tbl), tbl.shape[0]))
+        self._noise_dev_rows = tbl.shape[0]
+
+    def _grow_noise_if_needed(self):
+        """host_steps_bound counts steps since the last full reset: an upper bound of every
+        car's noise_step, kept on the host so that stepping never synchronises.  Only when the
+        bound reaches the table is the true maximum fetched (one tiny D2H copy per table-length
+        steps) and the table doubled if it is really needed."""
+        if self.noise is None or self.host_steps_bound + 1 < self._noise_dev_rows:
+            return
+        true_max = int(self.t['noise_step'].max().item())
+        if true_max + 2 >= self._noise_dev_rows:
+            self._upload_noise(2 * self._noise_dev_rows)
+        self.host_steps_bound = true_max
+
+    # ------------------------------------------------------------------ map / params
+    def set_map(self, map_path, map_ext):
+        m = load_map(map_path, map_ext)
+        self.set_map_data(m)
+        return True
+
+    def set_map_data(self, m):
+        _lib.check(self.lib.f110_set_map_occupancy(self._h, _np_ptr(m.free), m.height, m.width, m.resolution,
+                                                   m.orig_x, m.orig_y, m.orig_c, m.orig_s))
+        self.map = m
+
+    def set_map_dt(self, dt, resolution, orig_x, orig_y, orig_c=1.0, orig_s=0.0):
+        dt = np.ascontiguousarray(dt, dtype=np.float64)
+        _lib.check(self.lib.f110_set_map_dt(self._h, _np_ptr(dt), dt.shape[0], dt.shape[1], float(resolution),
+                                            float(orig_x), float(orig_y), float(orig_c), float(orig_s)))
+        self.map = ('dt', dt.shape)
+
+    def get_map_dt(self):
+        if self.map is None:
+            raise ValueError('Map is not set for scan simulator.')
+        shape = (self.map.height, self.map.width) if not isinstance(self.map, tuple) else self.map[1]
+        out = np.empty(shape, dtype=np.float64)
+        _lib.check(self.lib.f110_get_map_dt(self._h, _np_ptr(out)))
+        return out
+
+    def update_params(self, params):
+        self.params = dict(params)
+        pv = params_vec(self.params)
+        _lib.check(self.lib.f110_update_params(self._h, _np_ptr(pv)))
+
+    # ------------------------------------------------------------------ step path
+    def reset(self, poses, mask=None):
+        """poses: [B,A,3] float64 tensor on the device; mask: [B] uint8 tensor or None."""
+        if tuple(poses.shape) != (self.B, self.A, 3):
+            raise ValueError('Number of poses for reset does not match number of agents.')
+        poses = poses.to(device=self.device, dtype=torch.float64).contiguous()
+        if mask is not None:
+            mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
+        else:
+            self.host_steps_bound = 0
+        _lib.check(self.lib.f110_reset(self._h, _ptr(poses), _ptr(mask), self._stream()))
+        self.host_steps_bound += 1
+        self._keep = (poses, mask)  # keep inputs alive until the stream has consumed them
+
+    def step(self, actions):
+        """actions: [B,A,2] float64 tensor on the device (steer, speed)."""
+        if tuple(actions.shape) != (self.B, self.A, 2):
+            raise ValueError('actions must have shape (%d, %d, 2)' % (self.B, self.A))
+        if actions.dtype != torch.float64 or not actions.is_contiguous() or actions.device != self.device:
+            actions = actions.to(device=self.device, dtype=torch.float64).contiguous()
+        self._grow_noise_if_needed()
+        _lib.check(self.lib.f110_step(self._h, _ptr(actions), self._stream()))
+        self.host_steps_bound += 1
+        self._keep = actions
+
+    # ------------------------------------------------------------------ function-level entry points
+    def _dev64(self, a, shape=None):
+        t = torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64)) if not torch.is_tensor(a) else a
+        t = t.to(device=self.device, dtype=torch.float64).contiguous()
+        return t.reshape(shape) if shape is not None else t
+
+    def scan(self, poses, want_f32=False, want_lookups=False):
+        poses = self._dev64(poses, (-1, 3))
+        n = poses.shape[0]
+        out = torch.empty((n, self.num_beams), dtype=torch.float64, device=self.device)
+        out32 = torch.empty((n, self.num_beams), dtype=torch.float32, device=self.device) if want_f32 else None
+        lk = torch.zeros((n,), dtype=torch.int32, device=self.device) if want_lookups else None
+        _lib.check(self.lib.f110_scan(self._h, _ptr(poses), n, _ptr(out), _ptr(out32), _ptr(lk), self._stream()))
+        res = [out]
+        if want_f32:
+            res.append(out32)
+        if want_lookups:
+            res.append(lk)
+        return res[0] if len(res) == 1 else tuple(res)
+
+    def update_pose(self, state, steer_buf, steer_cnt, actions):
+        state, steer_buf = self._dev64(state, (-1, 7)).clone(), self._dev64(steer_buf, (-1, 2)).clone()
+        cnt = torch.as_tensor(np.asarray(steer_cnt)).to(device=self.device, dtype=torch.int32).contiguous().clone()
+        actions = self._dev64(actions, (-1, 2))
+        _lib.check(self.lib.f110_update_pose(self._h, _ptr(state), _ptr(steer_buf), _ptr(cnt), _ptr(actions),
+                                             state.shape[0], self._stream()))
+        return state, steer_buf, cnt
+
+    def get_vertices(self, poses):
+        poses = self._dev64(poses, (-1, 3))
+        out = torch.empty((poses.shape[0], 4, 2), dtype=torch.float64, device=self.device)
+        _lib.check(self.lib.f110_get_vertices(self._h, _ptr(poses), poses.shape[0], _ptr(out), self._stream()))
+        return out
+
+    def gjk_pairs(self, va, vb):
+        va, vb = self._dev64(va, (-1, 4, 2)), self._dev64(vb, (-1, 4, 2))
+        hit = torch.zeros((va.shape[0],), dtype=torch.uint8, device=self.device)
+        _lib.check(self.lib.f110_gjk_pairs(self._h, _ptr(va), _ptr(vb), va.shape[0], _ptr(hit), self._stream()))
+        return hit
+
+    def collision_multiple(self, verts):
+        verts = self._dev64(verts)
+        n, A = verts.shape[0], verts.shape[1]
+        col = torch.zeros((n, A), dtype=torch.uint8, device=self.device)
+        idx = torch.zeros((n, A), dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.f110_collision_multiple(self._h, _ptr(verts), n, A, _ptr(col), _ptr(idx), self._stream()))
+        return col, idx
+
+    def check_ttc(self, scans, vel):
+        scans, vel = self._dev64(scans, (-1, self.num_beams)), self._dev64(vel, (-1,))
+        hit = torch.zeros((scans.shape[0],), dtype=torch.uint8, device=self.device)
+        _lib.check(self.lib.f110_check_ttc(self._h, _ptr(scans), _ptr(vel), scans.shape[0], _ptr(hit), self._stream()))
+        return hit
+
+    def ray_cast(self, ego_poses, opp_verts, scans):
+        ego, verts = self._dev64(ego_poses, (-1, 3)), self._dev64(opp_verts, (-1, 4, 2))
+        scans = self._dev64(scans, (-1, self.num_beams)).clone()
+        span = torch.zeros((ego.shape[0], 2), dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.f110_ray_cast(self._h, _ptr(ego), _ptr(verts), ego.shape[0], _ptr(scans), _ptr(span),
+                                          self._stream()))
+        return scans, span
+
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h:
+            torch.cuda.synchronize(self.device)
+            self.lib.f110_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def edt_squared(free_mask):
+    """Host exact squared EDT (the integer kernel of f110_set_map_occupancy)."""
+    lib = _lib.load()
+    free_mask = np.ascontiguousarray(free_mask, dtype=np.uint8)
+    out = np.empty(free_mask.shape, dtype=np.uint32)
+    _lib.check(lib.f110_edt_squared(_np_ptr(free_mask), free_mask.shape[0], free_mask.shape[1], _np_ptr(out)))
+    return out

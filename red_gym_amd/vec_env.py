@@ -1,0 +1,106 @@
+"""F110VecEnv: B independent F1TENTH envs stepped in lock-step on one MI355X.
+
+Same constructor keywords, observation keys and step order as the reference's
+F110Env (gym/f110_gym/envs/f110_env.py:100-157, :261-347), with a leading batch
+dimension and torch tensors instead of Python lists.  Nothing is computed here:
+reset/step enqueue the HIP kernels of libf110_hip.so on the current stream.
+"""
+import os
+
+import numpy as np
+import torch
+
+from .base_classes import Integrator
+from .engine import DEFAULT_PARAMS, Engine
+from .maps import BUILTIN_MAPS, builtin_map_yaml
+
+
+def resolve_map_path(map_name):
+    """f110_env.py:106-118: builtin names map to the packaged maps, anything else is
+    '<map>.yaml'."""
+    if map_name in BUILTIN_MAPS:
+        return builtin_map_yaml(map_name)
+    return map_name + '.yaml'
+
+
+class F110VecEnv(object):
+    def __init__(self, num_envs, map='vegas', map_ext='.png', params=None, num_agents=2, timestep=0.01,
+                 ego_idx=0, integrator=Integrator.RK4, fov=2 * np.pi, seed=12345, device=0, autoreset=True,
+                 num_beams=1080, noise_std=0.01, keep_f64_scans=False, count_lookups=False, **_ignored):
+        self.num_envs, self.num_agents = int(num_envs), int(num_agents)
+        self.map_name, self.map_ext = map, map_ext
+        self.map_path = resolve_map_path(map)
+        self.params = dict(DEFAULT_PARAMS if params is None else params)
+        self.timestep, self.ego_idx, self.seed = timestep, ego_idx, seed
+        self.eng = Engine(num_envs=num_envs, num_agents=num_agents, params=self.params, seed=seed, fov=fov,
+                          timestep=timestep, integrator=integrator, ego_idx=ego_idx, num_beams=num_beams,
+                          device=device, autoreset=autoreset, noise_std=noise_std,
+                          keep_f64_scans=keep_f64_scans, count_lookups=count_lookups)
+        self.eng.set_map(self.map_path, self.map_ext)
+        self.device = self.eng.device
+        t = self.eng.t
+        st = t['state']
+        # observation views (no copies): obs keys of base_classes.py:587-603 + f110_env.py:277-278
+        self._obs = {
+            'ego_idx': ego_idx,
+            'scans': t['scans'],
+            'poses_x': st[..., 0], 'poses_y': st[..., 1], 'poses_theta': st[..., 4],
+            'linear_vels_x': st[..., 3],
+            'linear_vels_y': torch.zeros((self.num_envs, self.num_agents), dtype=torch.float64, device=self.device),
+            'ang_vels_z': st[..., 5],
+            'collisions': t['collisions'],
+            'lap_times': t['lap_times'], 'lap_counts': t['lap_counts'],
+        }
+        if t['scans_f64'] is not None:
+            self._obs['scans_f64'] = t['scans_f64']
+        self._reward = torch.full((self.num_envs,), float(timestep), dtype=torch.float64, device=self.device)
+
+    def _result(self):
+        t = self.eng.t
+        done = t['done'].bool()
+        info = {'checkpoint_done': t['toggles'] >= 4, 'collision_idx': t['collision_idx'],
+                'current_time': t['current_time'], 'toggles': t['toggles']}
+        return self._obs, self._reward, done, info
+
+    def _as_dev(self, a, last):
+        if not torch.is_tensor(a):
+            a = torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64))
+        a = a.to(device=self.device, dtype=torch.float64)
+        if a.dim() == 2 and self.num_envs == 1:
+            a = a.unsqueeze(0)
+        if tuple(a.shape) != (self.num_envs, self.num_agents, last):
+            raise ValueError('expected shape (%d, %d, %d), got %s' % (self.num_envs, self.num_agents, last, tuple(a.shape)))
+        return a.contiguous()
+
+    def reset(self, poses, mask=None):
+        """poses [B,A,3] (x, y, yaw).  Returns (obs, reward, done, info) like the
+        reference's reset (which performs one zero-action step, f110_env.py:335-347).
+        mask [B]: reset only those envs (others keep running untouched)."""
+        try:
+            poses = self._as_dev(poses, 3)
+        except ValueError:
+            raise ValueError('Number of poses for reset does not match number of agents.')
+        self.eng.reset(poses, mask)
+        return self._result()
+
+    def step(self, actions):
+        """actions [B,A,2] = (steer, speed) per car (f110_env.py:261-302)."""
+        self.eng.step(self._as_dev(actions, 2))
+        return self._result()
+
+    def update_params(self, params, index=-1):
+        """base_classes.py:507-527; all cars of a batch share one parameter set."""
+        if index >= self.num_agents:
+            raise IndexError('Index given is out of bounds for list of agents.')
+        self.params = dict(params)
+        self.eng.update_params(self.params)
+
+    def update_map(self, map_path, map_ext):
+        self.eng.set_map(map_path, map_ext)
+
+    @property
+    def state(self):
+        return self.eng.t['state']
+
+    def close(self):
+        self.eng.close()

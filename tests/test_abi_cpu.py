@@ -1,0 +1,91 @@
+"""No-GPU checks of the shipped library: it builds, loads, exports every symbol
+that include/f110_hip.h declares, and its host-only entry point (exact EDT)
+reproduces scipy's distance transform on every bundled map."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from red_gym_amd import _lib, build
+from red_gym_amd.maps import load_map
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def lib():
+    build.build()
+    return _lib.load()
+
+
+def test_header_symbols_all_exported(lib):
+    hdr = open(os.path.join(ROOT, 'include', 'f110_hip.h')).read()
+    declared = set(re.findall(r'\b(f110_[a-z0-9_]+)\s*\(', hdr))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    for name in declared:
+        assert getattr(lib, name) is not None
+
+
+def test_struct_layouts_match_header():
+    hdr = open(os.path.join(ROOT, 'include', 'f110_hip.h')).read()
+    body = hdr[hdr.index('typedef struct {', hdr.index('Caller-owned device buffers')):hdr.index('} f110_buffers;')]
+    fields = re.findall(r'\*\s*([a-z_0-9]+);', body)
+    assert fields == _lib.BUFFER_FIELDS
+    assert C.sizeof(_lib.Config) == 8 * 4 + 5 * 8 + 18 * 8
+
+
+def test_error_reporting_without_gpu(lib):
+    # argument validation happens before any HIP call
+    rc = lib.f110_create(None, None)
+    assert rc == _lib.E_INVALID and b'null' in lib.f110_last_error()
+    with pytest.raises(ValueError):
+        _lib.check(rc)
+    out = np.zeros((4, 4), dtype=np.uint32)
+    ones = np.ones((4, 4), dtype=np.uint8)
+    rc = lib.f110_edt_squared(ones.ctypes.data_as(C.c_void_p), 4, 4, out.ctypes.data_as(C.c_void_p))
+    assert rc == _lib.E_INVALID  # no occupied cell
+
+
+@pytest.mark.parametrize('rel', ['example_map.yaml', 'maps/berlin.yaml', 'maps/skirk.yaml', 'maps/vegas.yaml'])
+def test_exact_edt_equals_scipy(lib, assets, rel):
+    from scipy.ndimage import distance_transform_edt as edt
+    from red_gym_amd.engine import edt_squared
+    m = load_map(os.path.join(assets, rel), '.png')
+    d2 = edt_squared(m.free)
+    ref = m.resolution * edt(m.free.astype(np.float64) * 255.)  # laser_models.py:52,425
+    assert np.array_equal(m.resolution * np.sqrt(d2.astype(np.float64)), ref)
+
+
+def test_exact_edt_small_cases(lib):
+    from scipy.ndimage import distance_transform_edt as edt
+    from red_gym_amd.engine import edt_squared
+    rng = np.random.default_rng(5)
+    for shape in [(1, 1), (1, 7), (9, 1), (5, 8), (33, 17), (64, 64)]:
+        for dens in (0.02, 0.3, 0.9):
+            free = (rng.uniform(size=shape) > dens).astype(np.uint8)
+            free.flat[rng.integers(free.size)] = 0
+            d2 = edt_squared(free)
+            assert np.array_equal(np.sqrt(d2.astype(np.float64)), edt(free))
+
+
+def test_map_loader_matches_oracle_loader(assets):
+    import oracle
+    for rel in ['example_map.yaml', 'maps/skirk.yaml']:
+        m = load_map(os.path.join(assets, rel), '.png')
+        o = oracle.load_map(os.path.join(assets, rel), '.png')
+        assert (m.height, m.width, m.resolution) == (o['height'], o['width'], o['resolution'])
+        assert (m.orig_x, m.orig_y, m.orig_c, m.orig_s) == (o['orig_x'], o['orig_y'], o['orig_c'], o['orig_s'])
+        assert np.array_equal(m.free * 255., o['img'])
+
+
+def test_product_never_imports_oracle():
+    """The shipped package must not reference oracle/ (judge rule: no CPU fallback)."""
+    pkg = os.path.join(ROOT, 'red_gym_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.h', '.hip', '.cpp')):
+                src = open(os.path.join(dirpath, f)).read()
+                assert 'import oracle' not in src and 'from oracle' not in src, f
+                assert 'f110_oracle' not in src, f

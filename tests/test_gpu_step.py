@@ -1,0 +1,190 @@
+"""Step-path parity on the GPU: f110_reset / f110_step through the C ABI against
+the oracle's Env and the reference-generated trajectories (g7, g8)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import oracle  # noqa: E402
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _mk_oracle_env(assets, A, noise_steps, integrator=oracle.RK4):
+    sc = oracle.Scanner(1080, 2 * np.pi)
+    sc.set_map(os.path.join(assets, 'example_map.yaml'), '.png')
+    return oracle.Env(sc, A, noise=oracle.noise_table(12345, noise_steps), integrator=integrator)
+
+
+def _vec(assets, B, A, **kw):
+    from red_gym_amd import F110VecEnv
+    kw.setdefault('autoreset', False)
+    return F110VecEnv(B, map=os.path.join(assets, 'example_map'), map_ext='.png', num_agents=A,
+                      keep_f64_scans=True, **kw)
+
+
+def test_sim_step_one_agent_golden(golden, assets):
+    g = golden('g7_sim.npz')
+    env = _vec(assets, 1, 1)
+    env.reset(g['a1_start'][None])
+    T = g['a1_actions'].shape[0]
+    scan_at = dict(zip(g['a1_scan_steps'].tolist(), g['a1_scans']))
+    for k in range(T):
+        obs, _, done, info = env.step(g['a1_actions'][k][None])
+        assert np.allclose(_np(env.state)[0], g['a1_states'][k], rtol=0, atol=1e-9), k
+        assert np.array_equal(_np(obs['collisions'])[0].astype(np.float64), g['a1_collisions'][k]), k
+        if k in scan_at:
+            assert np.allclose(_np(obs['scans_f64'])[0, 0], scan_at[k], rtol=0, atol=1e-9), k
+            assert np.allclose(_np(obs['scans'])[0, 0], scan_at[k], rtol=0, atol=1e-5), k
+    env.close()
+
+
+def test_sim_step_two_agents_golden(golden, assets):
+    g = golden('g7_sim.npz')
+    env = _vec(assets, 1, 2)
+    env.reset(g['a2_start'][None])
+    T = g['a2_actions'].shape[0]
+    scan_at = dict(zip(g['a2_scan_steps'].tolist(), g['a2_scans']))
+    for k in range(T):
+        obs, _, done, info = env.step(g['a2_actions'][k][None])
+        assert np.allclose(_np(env.state)[0], g['a2_states'][k], rtol=0, atol=1e-9), k
+        assert np.array_equal(_np(obs['collisions'])[0].astype(np.float64), g['a2_collisions'][k]), k
+        assert np.array_equal(_np(info['collision_idx'])[0].astype(np.float64), g['a2_collision_idx'][k]), k
+        if k in scan_at:
+            assert np.allclose(_np(obs['scans_f64'])[0], scan_at[k], rtol=0, atol=1e-9), k
+    env.close()
+
+
+def test_env_closed_loop_golden(golden, assets):
+    """Config 1: the 2-lap waypoint-follow run (3329 steps, 2 laps, no collision)
+    replayed through the single-env F110Env facade."""
+    from red_gym_amd import F110Env, Integrator
+    g = golden('g8_env.npz')
+    env = F110Env(map=os.path.join(assets, 'example_map'), map_ext='.png', num_agents=1, timestep=0.01,
+                  integrator=Integrator.RK4)
+    obs, r, done, info = env.reset(g['start'])
+    ro = g['reset_obs']
+    assert np.allclose([obs['poses_x'][0], obs['poses_y'][0], obs['poses_theta'][0], obs['linear_vels_x'][0]], ro[:4], atol=1e-12)
+    assert obs['lap_times'][0] == ro[4] and obs['lap_counts'][0] == ro[5] and r == 0.01 and not done
+    assert isinstance(obs['poses_x'], list) and isinstance(obs['poses_x'][0], float)
+    assert obs['scans'][0].dtype == np.float64 and obs['scans'][0].shape == (1080,)
+    assert np.allclose(obs['scans'][0], g['scans'][0], rtol=0, atol=1e-9)
+    scan_at = dict(zip(g['scan_steps'].tolist()[1:], g['scans'][1:]))
+    T = g['actions'].shape[0]
+    laptime = 0.0
+    for k in range(T):
+        obs, r, done, info = env.step(g['actions'][k][None, :])
+        laptime += r
+        assert abs(obs['poses_x'][0] - g['x'][k]) < 1e-7 and abs(obs['poses_y'][0] - g['y'][k]) < 1e-7, k
+        assert abs(obs['poses_theta'][0] - g['theta'][k]) < 1e-7 and abs(obs['linear_vels_x'][0] - g['vx'][k]) < 1e-7, k
+        assert obs['collisions'][0] == g['col'][k], k
+        assert env.toggle_list[0] == g['toggle'][k], k
+        assert obs['lap_counts'][0] == g['lap_c'][k] and obs['lap_times'][0] == g['lap_t'][k], k
+        assert done == bool(g['done'][k]), k
+        assert bool(info['checkpoint_done'][0]) == (g['toggle'][k] >= 4)
+        if k in scan_at:
+            assert np.allclose(obs['scans'][0], scan_at[k], rtol=0, atol=1e-7), k
+    assert done and obs['lap_counts'][0] == 2 and abs(laptime - 33.29) < 1e-9
+    env.close()
+
+
+@pytest.mark.parametrize('A,integ', [(1, 'RK4'), (2, 'RK4'), (3, 'Euler')])
+def test_batched_random_rollout_vs_oracle(assets, A, integ):
+    """B envs with random actions for 60 steps, every env compared with an independent
+    oracle Env: collisions / collision_idx / toggles / lap counts exact, state and
+    scans to 1e-9."""
+    from red_gym_amd import Integrator
+    B, T = 24, 60
+    rl = np.loadtxt(os.path.join(assets, 'example_waypoints.csv'), delimiter=';', skiprows=3)
+    rng = np.random.default_rng(100 + A)
+    poses = np.zeros((B, A, 3))
+    for b in range(B):
+        k = (97 * b) % rl.shape[0]
+        for a in range(A):
+            kk = (k - 8 * a) % rl.shape[0]  # followers ~1.5 m behind along the raceline
+            poses[b, a] = [rl[kk, 1] + rng.normal(0, 0.1), rl[kk, 2] + rng.normal(0, 0.1),
+                           rl[kk, 3] + np.pi / 2 + rng.normal(0, 0.1)]
+    poses[0, :, :2] = poses[0, 0, :2]  # identical positions: GJK hit from the first step
+    env = _vec(assets, B, A, integrator=getattr(Integrator, integ))
+    ors = [_mk_oracle_env(assets, A, T + 2, oracle.RK4 if integ == 'RK4' else oracle.EULER) for _ in range(B)]
+    env.reset(poses)
+    oo = [ors[b].reset(poses[b]) for b in range(B)]
+
+    def compare(obs, info, done, oo, k):
+        st = _np(env.state)
+        for b in range(B):
+            assert np.allclose(st[b], oo[b]['state'], rtol=0, atol=1e-9), (k, b)
+            assert np.array_equal(_np(obs['collisions'])[b].astype(np.float64), oo[b]['collisions']), (k, b)
+            assert np.array_equal(_np(info['collision_idx'])[b].astype(np.float64), oo[b]['collision_idx']), (k, b)
+            assert np.array_equal(_np(info['toggles'])[b].astype(np.float64), oo[b]['toggles']), (k, b)
+            assert np.array_equal(_np(obs['lap_counts'])[b].astype(np.float64), oo[b]['lap_counts']), (k, b)
+            assert np.array_equal(_np(obs['lap_times'])[b], oo[b]['lap_times']), (k, b)
+            assert bool(_np(done)[b]) == oo[b]['done'], (k, b)
+            assert np.allclose(_np(obs['scans_f64'])[b], oo[b]['scans'], rtol=0, atol=1e-9), (k, b)
+    obs, _, done, info = env._result()
+    compare(obs, info, done, oo, -1)
+    hits = 0
+    for k in range(T):
+        act = np.stack([rng.uniform(-0.4189, 0.4189, (B, A)), rng.uniform(0, 8, (B, A))], axis=2)
+        obs, _, done, info = env.step(act)
+        oo = [ors[b].step(act[b]) for b in range(B)]
+        compare(obs, info, done, oo, k)
+        hits += int(_np(obs['collisions']).sum())
+    assert hits > 0 or A == 1  # identical start positions guarantee a GJK hit for A > 1
+    env.close()
+
+
+def test_autoreset_and_masked_reset(assets):
+    """done envs restart from their spawn pose on the next step (reset + zero-action
+    step, f110_env.py:304-347); a masked reset leaves the other envs untouched."""
+    B = 8
+    rl = np.loadtxt(os.path.join(assets, 'example_waypoints.csv'), delimiter=';', skiprows=3)
+    poses = np.stack([[rl[(97 * b) % 783, 1], rl[(97 * b) % 783, 2], rl[(97 * b) % 783, 3] + np.pi / 2] for b in range(B)])[:, None, :]
+    env = _vec(assets, B, 1, autoreset=True)
+    ors = [_mk_oracle_env(assets, 1, 400) for _ in range(B)]
+    env.reset(poses)
+    oo = [ors[b].reset(poses[b]) for b in range(B)]
+    pending = np.zeros(B, dtype=bool)
+    resets = 0
+    for k in range(150):
+        act = np.zeros((B, 1, 2))
+        act[:, 0, 0] = 0.3   # drive into the wall
+        act[:, 0, 1] = 6.0
+        obs, _, done, info = env.step(act)
+        for b in range(B):
+            if pending[b]:
+                oo[b] = ors[b].reset(poses[b])
+                resets += 1
+            else:
+                oo[b] = ors[b].step(act[b])
+            pending[b] = oo[b]['done']
+            assert bool(_np(done)[b]) == oo[b]['done'], (k, b)
+            assert np.allclose(_np(env.state)[b], oo[b]['state'], rtol=0, atol=1e-9), (k, b)
+            assert np.allclose(_np(obs['scans_f64'])[b], oo[b]['scans'], rtol=0, atol=1e-9), (k, b)
+            assert _np(info['current_time'])[b] == oo[b]['current_time']
+    assert resets >= B
+    # masked reset: env 2 only
+    import torch
+    before = _np(env.state).copy()
+    mask = torch.zeros(B, dtype=torch.uint8)
+    mask[2] = 1
+    env.reset(poses, mask=mask)
+    after = _np(env.state)
+    o2 = ors[2].reset(poses[2])
+    assert np.allclose(after[2], o2['state'], atol=1e-9)
+    keep = [b for b in range(B) if b != 2]
+    assert np.array_equal(after[keep], before[keep])
+    env.close()
+
+
+def test_reset_errors(assets):
+    env = _vec(assets, 2, 2)
+    with pytest.raises(ValueError, match='Number of poses'):
+        env.reset(np.zeros((2, 3, 3)))
+    with pytest.raises(IndexError):
+        env.update_params(env.params, index=5)
+    env.close()
