@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/s of the batched F110Env.step path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs B] [--agents A]
+
+One "step" = one f110_step over all B envs of this rank (every car: single-track
+RK4, 1080-beam ray march, noise, iTTC, (GJK + opponent ray cast for A>1), lap
+logic, autoreset).  Default workload: BASELINE.json configs[2] = 65536 envs x 1
+agent per GPU on example_map (the config the metric's target is quoted on; N>1 is
+configs[4], independent shards, no collective on the step path).  Actions and all
+state are resident in HBM before the timed region.  Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def cpu_baseline(num_agents, budget_s=12.0):
+    """The CPU oracle (oracle/f110_oracle.c, a scalar fp64 port of the reference's
+    Numba path) timed on this box's host cores on a bounded sample of the same
+    workload: same map, spawn distribution, action distribution, noise, autoreset."""
+    import oracle
+    from red_gym_amd import workload
+    cores = len(os.sched_getaffinity(0))
+    sc = oracle.Scanner(1080, 2 * np.pi)
+    sc.set_map(workload.EXAMPLE_MAP + '.yaml', '.png')
+    B = 64 * cores
+    noise = oracle.noise_table(12345, 4096)
+    batch = oracle.Batch(sc, B, num_agents, workload.spawn_poses(B, num_agents), noise=noise)
+    acts = workload.action_pool(8, B, num_agents)
+    batch.step(acts[0], threads=cores)  # reset step (untimed)
+    t0 = time.perf_counter()
+    steps = 0
+    while True:
+        batch.step(acts[steps % 8], threads=cores)
+        steps += 1
+        if time.perf_counter() - t0 > budget_s or steps >= 400:
+            break
+    dt = time.perf_counter() - t0
+    # single-thread figure (the reference itself is single-threaded) on a smaller sample
+    b1 = oracle.Batch(sc, 64, num_agents, workload.spawn_poses(64, num_agents), noise=noise)
+    a1 = workload.action_pool(4, 64, num_agents)
+    b1.step(a1[0], threads=1)
+    t1 = time.perf_counter()
+    for k in range(6):
+        b1.step(a1[k % 4], threads=1)
+    dt1 = time.perf_counter() - t1
+    return {'value': B * steps / dt, 'unit': 'env-steps/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d envs x %d agent(s) x %d steps (OpenMP over envs, %d threads), example_map, '
+                      'same spawn/action/noise distribution' % (B, num_agents, steps, cores),
+            'single_thread_value': 64 * 6 / dt1}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=50)
+    ap.add_argument('--envs', type=int, default=65536, help='envs per GPU')
+    ap.add_argument('--agents', type=int, default=1)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-scan-events', action='store_true',
+                    help='do not bracket the scan kernel with hipEvents (roofline becomes null)')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit('bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)' % args.gpus)
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    from red_gym_amd import F110VecEnv, workload
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+
+    B, A, K, W = args.envs, args.agents, args.steps, args.warmup
+    env = F110VecEnv(B, map=workload.EXAMPLE_MAP, map_ext='.png', num_agents=A, timestep=0.01, seed=12345,
+                     device=local_rank, autoreset=True, count_lookups=True)
+    poses = torch.as_tensor(workload.spawn_poses(B, A, rank), device=dev)
+    POOL = 16
+    acts = torch.as_tensor(workload.action_pool(POOL, B, A, rank), device=dev)  # resident in HBM
+    env.reset(poses)
+    for k in range(W):
+        env.step(acts[k % POOL])
+    lookups = env.eng.t['lookups']
+    lookups.zero_()
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+        torch.cuda.synchronize(dev)
+
+    if not args.no_scan_events:
+        env.eng.profile_begin(K)
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(K):
+        env.step(acts[(W + k) % POOL])
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier(device_ids=[local_rank])
+        torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    out = None
+    if rank == 0:
+        value = world * B * K / elapsed
+        roof = None
+        if not args.no_scan_events:
+            scan_ms, n_launch = env.eng.profile_end()
+            tot_lookups = int(lookups.to(torch.int64).sum().item())
+            cars = B * A
+            # SURVEY 8(d) byte model, per car-step: L*4 + 1080*4 + 72
+            bytes_per_launch = (tot_lookups / max(n_launch, 1)) * 4.0 + cars * (1080 * 4 + 72)
+            avg_s = scan_ms * 1e-3 / max(n_launch, 1)
+            achieved = bytes_per_launch / avg_s / 1e9
+            traffic = None
+            tp = os.path.join(ROOT, 'profiles', 'traffic.json')
+            if os.path.exists(tp):
+                tj = json.load(open(tp))
+                key = '%dx%d' % (B, A)
+                if key in tj:
+                    traffic = tj[key]['hbm_bytes_per_launch']
+            roof = {'bound': 'hbm', 'kernel': 'scan_kernel', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
+                    'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                    'avg_launch_ms': avg_s * 1e3, 'launches': n_launch,
+                    'lookups_per_car_step': tot_lookups / max(n_launch, 1) / cars,
+                    'algorithmic_bytes_per_launch': bytes_per_launch}
+        out = {'metric': 'env steps/sec (all envs), 1080-beam lidar', 'value': value, 'unit': 'env-steps/s',
+               'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': elapsed / K * 1e3,
+               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
+               'data': 'synthetic',
+               'config': {'workload': '%d envs x %d agent(s) per GPU, example_map, 1080 beams, RK4 single-track, '
+                                      'noise+iTTC%s, lap logic, autoreset; random actions'
+                                      % (B, A, '+GJK+opponent ray-cast' if A > 1 else ''),
+                          'envs_per_gpu': B, 'agents': A, 'num_beams': 1080, 'map': 'example_map',
+                          'sharding': 'independent env shards, no collective on the step path'},
+               'roofline': roof}
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(A)
+    env.close()
+    if world > 1:
+        dist.barrier(device_ids=[local_rank])
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == '__main__':
+    main()

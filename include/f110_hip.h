@@ -88,7 +88,8 @@ typedef struct {
     int32_t *lap_counts;    /* [N]    f110_env.py:238 */
     double *lap_times;      /* [N]    f110_env.py:240 */
     uint8_t *done;          /* [B]    f110_env.py:242 */
-    uint32_t *lookups;      /* [N]    distance-table reads of this step per car (instrumentation), or NULL */
+    uint32_t *lookups;      /* [N]    distance-table reads per car, ACCUMULATED over steps until the caller
+                                      zeroes it (instrumentation for the byte model), or NULL */
 } f110_buffers;
 
 int f110_create(const f110_config *cfg, f110_handle **out);
@@ -141,9 +142,17 @@ int f110_reset(f110_handle *h, const double *poses_dev, const uint8_t *mask_dev,
  * ignore their action and perform reset(spawn) + zero-action step instead. */
 int f110_step(f110_handle *h, const double *actions_dev, void *stream);
 
+/* Measurement aid (bench.py): between begin and end every f110_step brackets its
+ * scan_kernel launch with a hipEvent pair on the step's stream (up to max_launches
+ * steps).  f110_profile_end synchronises on the last event and returns the summed
+ * kernel time in milliseconds and the number of launches measured. */
+int f110_profile_begin(f110_handle *h, int32_t max_launches);
+int f110_profile_end(f110_handle *h, double *scan_ms_total, int32_t *launches);
+
 /* ---- function-level entry points (parity tests; all pointers dev) ---- */
 /* ScanSimulator2D.scan(pose, None): n poses [n,3] -> [n,num_beams] (noise off).
- * scans_f32 / lookups may be NULL. */
+ * scans_f32 / lookups may be NULL; lookups [n] is overwritten-by-accumulation like
+ * f110_buffers.lookups (zero it first). */
 int f110_scan(f110_handle *h, const double *poses, int32_t n, double *scans_f64, float *scans_f32,
               uint32_t *lookups, void *stream);
 /* RaceCar.update_pose without the scan (base_classes.py:254-402), n cars in place. */

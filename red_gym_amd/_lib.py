@@ -51,6 +51,8 @@ SYMBOLS = {
     'f110_bind': [_VP, C.POINTER(Buffers)],
     'f110_reset': [_VP, _VP, _VP, _VP],
     'f110_step': [_VP, _VP, _VP],
+    'f110_profile_begin': [_VP, _I32],
+    'f110_profile_end': [_VP, C.POINTER(C.c_double), C.POINTER(C.c_int32)],
     'f110_scan': [_VP, _VP, _I32, _VP, _VP, _VP, _VP],
     'f110_update_pose': [_VP, _VP, _VP, _VP, _VP, _I32, _VP],
     'f110_get_vertices': [_VP, _VP, _I32, _VP, _VP],
@@ -78,6 +80,11 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError('%s not found: build it with `python -m red_gym_amd.build` '
                           '(hipcc --offload-arch=gfx950); there is no CPU fallback.' % LIB_PATH)
+    # torch bundles its own libamdhip64 (soname libamdhip64.so.7).  It must be in the
+    # process BEFORE this library is loaded so that both share ONE HIP runtime (ours then
+    # binds to the already-loaded soname); the other order maps a second runtime, which
+    # cannot see the device.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, argtypes in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol

@@ -47,6 +47,10 @@ struct f110_handle {
     MapDev map;
     bool ident = false, pow2 = false;
     double theta_inc = 0;
+    // measurement aid (f110_profile_begin/end)
+    std::vector<hipEvent_t> prof_ev; // pairs: [2*i] before, [2*i+1] after the scan launch
+    int prof_n = 0;
+    bool prof_on = false;
 };
 
 extern "C" const char *f110_last_error(void) { return g_err; }
@@ -205,6 +209,7 @@ extern "C" void f110_destroy(f110_handle *h)
                     h->d_cells, h->d_lut, h->d_dt, h->d_noise};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
     delete h;
 }
 
@@ -395,8 +400,11 @@ static int run_step(f110_handle *h, const double *actions, int reset_only, hipSt
     s.ttc_thresh = c.ttc_thresh; s.car_length = h->params.v[P_LENGTH]; s.car_width = h->params.v[P_WIDTH];
     s.in_collision = b.in_collision; s.pending_reset = b.pending_reset; s.reset_only = reset_only;
     s.out_f32 = b.scans; s.out_f64 = b.scans_f64; s.lookups = b.lookups;
+    const bool prof = h->prof_on && (size_t)(2 * h->prof_n + 1) < h->prof_ev.size();
+    if (prof) HIP_TRY(hipEventRecord(h->prof_ev[2 * h->prof_n], st));
     int rc = launch_scan(h, s, st);
     if (rc) return rc;
+    if (prof) { HIP_TRY(hipEventRecord(h->prof_ev[2 * h->prof_n + 1], st)); h->prof_n++; }
 
     EnvArgs e;
     e.n_envs = c.num_envs; e.agents = c.num_agents; e.ego_idx = c.ego_idx; e.autoreset = c.autoreset;
@@ -448,6 +456,43 @@ extern "C" int f110_step(f110_handle *h, const double *actions, void *stream)
     if (rc) return rc;
     if (!actions) return fail(F110_E_INVALID, "f110_step: null actions");
     return run_step(h, actions, 0, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------- measurement aid
+static void prof_clear(f110_handle *h)
+{
+    for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
+    h->prof_ev.clear();
+    h->prof_n = 0;
+    h->prof_on = false;
+}
+
+extern "C" int f110_profile_begin(f110_handle *h, int32_t max_launches)
+{
+    if (!h || max_launches < 1 || max_launches > (1 << 20)) return fail(F110_E_INVALID, "f110_profile_begin: bad arguments");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    prof_clear(h);
+    h->prof_ev.resize((size_t)2 * max_launches);
+    for (auto &e : h->prof_ev) HIP_TRY(hipEventCreate(&e));
+    h->prof_on = true;
+    return F110_OK;
+}
+
+extern "C" int f110_profile_end(f110_handle *h, double *ms_total, int32_t *launches)
+{
+    if (!h || !ms_total || !launches) return fail(F110_E_INVALID, "f110_profile_end: null argument");
+    if (!h->prof_on) return fail(F110_E_INVALID, "f110_profile_end: f110_profile_begin has not been called");
+    double tot = 0;
+    if (h->prof_n > 0) HIP_TRY(hipEventSynchronize(h->prof_ev[2 * h->prof_n - 1]));
+    for (int i = 0; i < h->prof_n; i++) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, h->prof_ev[2 * i], h->prof_ev[2 * i + 1]));
+        tot += ms;
+    }
+    *ms_total = tot;
+    *launches = h->prof_n;
+    prof_clear(h);
+    return F110_OK;
 }
 
 // ---------------------------------------------------------------- function-level entry points

@@ -192,7 +192,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanArgs a)
         unsigned tot = nlook;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
-        if (lane == 0) a.lookups[car] = tot + (unsigned)nb;
+        if (lane == 0) a.lookups[car] += tot + (unsigned)nb;
     }
 
     // ---- noise + iTTC (laser_models.py:450-452, :189-217; base_classes.py:227-252) ----

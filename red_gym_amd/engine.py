@@ -285,6 +285,15 @@ class Engine(object):
                                           self._stream()))
         return scans, span
 
+    # ------------------------------------------------------------------ measurement aid
+    def profile_begin(self, max_launches):
+        _lib.check(self.lib.f110_profile_begin(self._h, int(max_launches)))
+
+    def profile_end(self):
+        ms, n = C.c_double(0), C.c_int32(0)
+        _lib.check(self.lib.f110_profile_end(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
     def close(self):
         if getattr(self, '_h', None) is not None and self._h:
             torch.cuda.synchronize(self.device)
