@@ -353,7 +353,7 @@ static ScanDev scan_dev(const f110_handle *h)
 {
     ScanDev s;
     s.nb = h->cfg.num_beams; s.theta_dis = h->cfg.theta_dis; s.fov = h->cfg.fov; s.eps = h->cfg.eps;
-    s.max_range = h->cfg.max_range; s.inc = h->theta_inc; s.sines = h->d_sines; s.cosines = h->d_cosines;
+    s.max_range = h->cfg.max_range; s.inc = h->theta_inc; s.inv_td = 1.0 / h->cfg.theta_dis; s.sines = h->d_sines; s.cosines = h->d_cosines;
     return s;
 }
 
@@ -405,6 +405,14 @@ static int run_step(f110_handle *h, const double *actions, int reset_only, hipSt
     int rc = launch_scan(h, s, st);
     if (rc) return rc;
     if (prof) { HIP_TRY(hipEventRecord(h->prof_ev[2 * h->prof_n + 1], st)); h->prof_n++; }
+    if (c.num_agents > 1) {
+        OppArgs o;
+        o.n_cars = N; o.agents = c.num_agents; o.nb = c.num_beams; o.state = b.state; o.pose_snap = b.pose_snap;
+        o.scan_angles = h->d_scan_angles; o.car_length = h->params.v[P_LENGTH]; o.car_width = h->params.v[P_WIDTH];
+        o.pending_reset = b.pending_reset; o.reset_only = reset_only; o.scans32 = b.scans; o.scans64 = b.scans_f64;
+        hipLaunchKernelGGL(opponents_kernel, dim3((N + 3) / 4), dim3(256), 0, st, o);
+        HIP_TRY(hipGetLastError());
+    }
 
     EnvArgs e;
     e.n_envs = c.num_envs; e.agents = c.num_agents; e.ego_idx = c.ego_idx; e.autoreset = c.autoreset;

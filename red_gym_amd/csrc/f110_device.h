@@ -331,10 +331,12 @@ __device__ inline void blocked_view_indices(double px, double py, double pyaw, c
     max_ind = hi;
 }
 
-// laser_models.py:319-346 on a wave: beams strided over lanes; `scan` may be LDS or global
+// laser_models.py:319-346 on a wave: beams strided over lanes.  The scan lives in
+// global memory as fp64 and/or fp32; (float)min(a, b) == min((float)a, (float)b)
+// because rounding is monotonic, so the fp32 observation can be updated in place.
 __device__ inline void ray_cast_wave(double px, double py, double pyaw, const double verts[4][2],
                                      const double *__restrict__ scan_angles, int nb, int lane,
-                                     double *scan, int *span_out)
+                                     double *scan64, float *scan32, int *span_out)
 {
     int min_ind, max_ind;
     blocked_view_indices(px, py, pyaw, verts, scan_angles, nb, lane, min_ind, max_ind);
@@ -343,14 +345,15 @@ __device__ inline void ray_cast_wave(double px, double py, double pyaw, const do
     for (int i = min_ind + lane; i <= max_ind; i += 64) {
         double bt = (pyaw + scan_angles[i]) + F110_PI / 2.;
         double v3x = cos(bt), v3y = sin(bt);
-        double cur = scan[i];
+        double best = __builtin_inf();
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             int jn = (j + 1) & 3;
             double r = get_range(px, py, v3x, v3y, verts[j][0], verts[j][1], verts[jn][0], verts[jn][1]);
-            if (r < cur) cur = r;
+            if (r < best) best = r;
         }
-        scan[i] = cur;
+        if (scan64) { double cur = scan64[i]; if (best < cur) scan64[i] = best; }
+        if (scan32) { float cur = scan32[i]; float b32 = (float)best; if (b32 < cur) scan32[i] = b32; }
     }
 }
 

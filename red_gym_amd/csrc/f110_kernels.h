@@ -28,6 +28,7 @@ struct MapDev {
 struct ScanDev {
     int nb, theta_dis;
     double fov, eps, max_range, inc; // inc = theta_index_increment (laser_models.py:368)
+    double inv_td;                   // 1 / theta_dis
     const double *sines, *cosines;   // [theta_dis] (laser_models.py:379-381)
 };
 
@@ -55,11 +56,14 @@ __device__ inline double dist_lookup(const MapDev &m, const double *lds_lut, dou
     ci = ci < 0 ? 0 : (ci > m.W - 1 ? m.W - 1 : ci);
     ri = ri < 0 ? 0 : (ri > m.H - 1 ? m.H - 1 : ri);
     int idx = oob ? 0 : ri * m.W + ci;
-    unsigned code = m.cells[idx];
-    double d;
-    if (code < (unsigned)LUT_LDS) d = lds_lut[code];
-    else if (code != (unsigned)CODE_ESC) d = m.lut[code];
-    else d = m.dt[idx];
+    const unsigned code = m.cells[idx];
+    // common case (d2 < LUT_LDS, i.e. within ~2 m of a wall): one ds_read_b64
+    double d = lds_lut[code < (unsigned)LUT_LDS ? code : 0u];
+    // pin the LDS read: otherwise the compiler folds it and the rare global reads below
+    // into one flat_load through a selected generic pointer
+    asm volatile("" : "+v"(d));
+    if (__builtin_expect(code >= (unsigned)LUT_LDS, 0))
+        d = (code != (unsigned)CODE_ESC) ? m.lut[code] : m.dt[idx];
     return oob ? m.oob : d;
 }
 
@@ -71,7 +75,7 @@ __device__ inline int beam_theta_index(double t0w, int b, const ScanDev &s)
 {
     const double td = (double)s.theta_dis;
     double t = t0w + (double)b * s.inc;
-    t -= floor(t / td) * td;
+    t -= floor(t * s.inv_td) * td; // any error lands in the guard band below
     int idx = (int)t;
     double fr = t - (double)idx;
     if (!(fr > 1e-8 && fr < 1. - 1e-8) || idx < 0 || idx >= s.theta_dis) {
@@ -150,10 +154,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanArgs a)
         bool active = false;
         int beam = 0;
         double x = 0, y = 0, c = 0, s = 0, total = 0;
-        while (true) {
+        for (;;) {
+            // ---- refill phase: every idle lane takes the next unassigned beam ----
             const unsigned long long idle = __ballot(!active);
             const int nidle = __popcll(idle);
-            if (next < nb && (nidle >= REFILL_MIN_IDLE || nidle == WAVE)) {
+            if (next < nb) {
                 if (!active) {
                     const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32),
                                         __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
@@ -173,18 +178,25 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanArgs a)
             } else if (nidle == WAVE) {
                 break;
             }
-            if (active) {
-                const double d = dist_lookup<IDENT, POW2>(a.map, s_lut, x, y);
-                nlook++;
-                total += d;
-                if (d > eps && total <= max_range) {
-                    x += d * c;
-                    y += d * s;
-                } else {
-                    s_res[beam] = total > max_range ? max_range : total;
-                    active = false;
+            // ---- march phase: step all active rays until enough lanes are idle again
+            // (or, once no beams are left, until the wave has drained) ----
+            const int stop = next < nb ? REFILL_MIN_IDLE : WAVE;
+            int idle_now;
+            do {
+                if (active) {
+                    const double d = dist_lookup<IDENT, POW2>(a.map, s_lut, x, y);
+                    nlook++;
+                    total += d;
+                    if (d > eps && total <= max_range) {
+                        x += d * c;
+                        y += d * s;
+                    } else {
+                        s_res[beam] = total > max_range ? max_range : total;
+                        active = false;
+                    }
                 }
-            }
+                idle_now = __popcll(__ballot(!active));
+            } while (idle_now < stop);
         }
     }
     if (a.lookups) {
@@ -196,7 +208,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanArgs a)
     }
 
     // ---- noise + iTTC (laser_models.py:450-452, :189-217; base_classes.py:227-252) ----
-    double ryaw = yaw;
     if (a.state) {
         double *st = a.state + (size_t)car * 7;
         const double vel = st[3];
@@ -222,18 +233,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanArgs a)
             a.in_collision[car] = any_hit ? 1 : 0;
             a.noise_step[car] += 1;
         }
-        if (any_hit) ryaw = 0.;
-        // ---- opponents (base_classes.py:204-225): own current pose vs snapshot poses ----
-        if (a.agents > 1) {
-            const int a0 = env * a.agents;
-            for (int j = 0; j < a.agents; j++) {
-                if (a0 + j == car) continue;
-                const double *op = a.pose_snap + (size_t)(a0 + j) * 3;
-                double verts[4][2];
-                get_vertices(op[0], op[1], op[2], a.car_length, a.car_width, verts);
-                ray_cast_wave(px, py, ryaw, verts, a.scan_angles, nb, lane, s_res, nullptr);
-            }
-        }
     }
 
     // ---- coalesced write-out -------------------------------------------------------
@@ -244,6 +243,42 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanArgs a)
     if (a.out_f64) {
         double *o = a.out_f64 + (size_t)car * nb;
         for (int i = lane; i < nb; i += WAVE) o[i] = s_res[i];
+    }
+}
+
+// ------------------------------------------------------------------ opponents (wave per car, A > 1)
+// RaceCar.ray_cast_agents (base_classes.py:204-225): the car's CURRENT pose (yaw already
+// zeroed by an iTTC hit, :245) against the other cars' post-integration snapshot poses.
+// Kept out of scan_kernel so that the march loop stays at ~34 VGPRs.
+struct OppArgs {
+    int n_cars, agents, nb;
+    const double *state;      // [N,7]
+    const double *pose_snap;  // [N,3]
+    const double *scan_angles;
+    double car_length, car_width;
+    const uint8_t *pending_reset;
+    int reset_only;
+    float *scans32;           // [N,nb] or NULL
+    double *scans64;          // [N,nb] or NULL
+};
+
+__global__ __launch_bounds__(256) void opponents_kernel(OppArgs a)
+{
+    const int car = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (car >= a.n_cars) return;
+    const int env = car / a.agents;
+    if (a.reset_only && !a.pending_reset[env]) return;
+    const double *st = a.state + (size_t)car * 7;
+    const double px = st[0], py = st[1], pyaw = st[4];
+    const int a0 = env * a.agents;
+    for (int j = 0; j < a.agents; j++) {
+        if (a0 + j == car) continue;
+        const double *op = a.pose_snap + (size_t)(a0 + j) * 3;
+        double verts[4][2];
+        get_vertices(op[0], op[1], op[2], a.car_length, a.car_width, verts);
+        ray_cast_wave(px, py, pyaw, verts, a.scan_angles, a.nb, lane,
+                      a.scans64 ? a.scans64 + (size_t)car * a.nb : nullptr,
+                      a.scans32 ? a.scans32 + (size_t)car * a.nb : nullptr, nullptr);
     }
 }
 
@@ -475,7 +510,7 @@ __global__ void ray_cast_kernel(const double *ego, const double *verts, int n, i
     double v[4][2];
     for (int k = 0; k < 4; k++) { v[k][0] = verts[(size_t)row * 8 + 2 * k]; v[k][1] = verts[(size_t)row * 8 + 2 * k + 1]; }
     ray_cast_wave(ego[3 * row], ego[3 * row + 1], ego[3 * row + 2], v, scan_angles, nb, lane,
-                  scans + (size_t)row * nb, span ? span + 2 * row : nullptr);
+                  scans + (size_t)row * nb, nullptr, span ? span + 2 * row : nullptr);
 }
 
 } // namespace f110
