@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libf110_hip.so')
+LIB_PATH = os.environ.get('F110_LIB') or os.path.join(_HERE, 'libf110_hip.so')  # F110_LIB: kernel-variant sweeps
 
 F110_MAX_AGENTS = 8
 F110_NUM_PARAMS = 18

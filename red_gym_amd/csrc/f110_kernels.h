@@ -11,11 +11,17 @@
 namespace f110 {
 
 constexpr int WAVE = 64;
-constexpr int SCAN_WAVES = 8;                 // cars per workgroup (one wavefront each)
+#ifndef F110_SCAN_WAVES
+#define F110_SCAN_WAVES 8
+#endif
+#ifndef F110_REFILL_MIN_IDLE
+#define F110_REFILL_MIN_IDLE 16
+#endif
+constexpr int SCAN_WAVES = F110_SCAN_WAVES;   // cars per workgroup (one wavefront each)
 constexpr int SCAN_THREADS = SCAN_WAVES * WAVE;
 constexpr int LUT_LDS = 1024;                 // distance LUT entries staged in LDS (d2 < 1024)
 constexpr int CODE_ESC = 65535;               // cell code: read the fp64 table instead
-constexpr int REFILL_MIN_IDLE = 16;           // refill the wave's beam slots once this many lanes idle
+constexpr int REFILL_MIN_IDLE = F110_REFILL_MIN_IDLE; // refill the wave's beam slots once this many lanes idle
 
 struct MapDev {
     const uint16_t *cells;  // [H*W] min(d2, 65535); 65535 = escape to dt
