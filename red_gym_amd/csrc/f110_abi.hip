@@ -5,11 +5,13 @@
 #include "../../include/f110_hip.h"
 #include "f110_kernels.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <utility>
 #include <vector>
 
 using namespace f110;
@@ -40,7 +42,7 @@ struct f110_handle {
     // device tables owned by the handle
     double *d_sines = nullptr, *d_cosines = nullptr;
     double *d_scan_angles = nullptr, *d_beam_cosines = nullptr, *d_side = nullptr;
-    uint16_t *d_cells = nullptr;
+    uint16_t *d_cells = nullptr, *d_beam_order = nullptr;
     double *d_lut = nullptr, *d_dt = nullptr;
     double *d_noise = nullptr;
     long long noise_T = 0;
@@ -161,6 +163,23 @@ static int upload(double **dst, const double *src, size_t n)
     return F110_OK;
 }
 
+// Order in which a car's beams are handed to idle lanes.  Rays along the car's
+// longitudinal axis run down the track and need the most march steps, so they start
+// first and the short side rays fill the tail: beams sorted by |sin(angle)|, ties by index.
+static int set_beam_order(f110_handle *h)
+{
+    const int nb = h->cfg.num_beams;
+    const double incr = h->cfg.fov / (nb - 1);
+    std::vector<std::pair<double, int>> key(nb);
+    for (int i = 0; i < nb; i++) key[i] = {std::fabs(std::sin(-h->cfg.fov / 2. + i * incr)), i};
+    std::sort(key.begin(), key.end());
+    std::vector<uint16_t> order(nb);
+    for (int i = 0; i < nb; i++) order[i] = (uint16_t)key[i].second;
+    if (!h->d_beam_order) HIP_TRY(hipMalloc((void **)&h->d_beam_order, nb * sizeof(uint16_t)));
+    HIP_TRY(hipMemcpy(h->d_beam_order, order.data(), nb * sizeof(uint16_t), hipMemcpyHostToDevice));
+    return F110_OK;
+}
+
 extern "C" int f110_create(const f110_config *cfg, f110_handle **out)
 {
     if (!cfg || !out) return fail(F110_E_INVALID, "f110_create: null argument");
@@ -193,7 +212,7 @@ extern "C" int f110_create(const f110_config *cfg, f110_handle **out)
     if ((rc = upload(&h->d_sines, s.data(), s.size())) || (rc = upload(&h->d_cosines, c.data(), c.size())) ||
         (rc = upload(&h->d_scan_angles, ang.data(), ang.size())) ||
         (rc = upload(&h->d_beam_cosines, bcos.data(), bcos.size())) ||
-        (rc = upload(&h->d_side, side.data(), side.size()))) {
+        (rc = upload(&h->d_side, side.data(), side.size())) || (rc = set_beam_order(h))) {
         f110_destroy(h);
         return rc;
     }
@@ -206,7 +225,7 @@ extern "C" void f110_destroy(f110_handle *h)
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
     void *ptrs[] = {h->d_sines, h->d_cosines, h->d_scan_angles, h->d_beam_cosines, h->d_side,
-                    h->d_cells, h->d_lut, h->d_dt, h->d_noise};
+                    h->d_cells, h->d_lut, h->d_dt, h->d_noise, h->d_beam_order};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
@@ -359,16 +378,8 @@ static ScanDev scan_dev(const f110_handle *h)
 
 static int launch_scan(f110_handle *h, const ScanArgs &a, hipStream_t st)
 {
-    const int nb_pad = (a.scan.nb + 1) & ~1;
-    const size_t smem = (size_t)(LUT_LDS + SCAN_WAVES * nb_pad) * sizeof(double);
+    const size_t smem = 0; // the LUT is static LDS
     const dim3 grid((a.n_cars + SCAN_WAVES - 1) / SCAN_WAVES), block(SCAN_THREADS);
-    if (smem > 64 * 1024) {
-        // opt in to > 64 KiB of dynamic LDS (one workgroup may use up to 160 KiB on gfx950)
-        HIP_TRY(hipFuncSetAttribute((const void *)scan_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        HIP_TRY(hipFuncSetAttribute((const void *)scan_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        HIP_TRY(hipFuncSetAttribute((const void *)scan_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        HIP_TRY(hipFuncSetAttribute((const void *)scan_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    }
     if (h->ident && h->pow2) hipLaunchKernelGGL((scan_kernel<true, true>), grid, block, smem, st, a);
     else if (h->ident) hipLaunchKernelGGL((scan_kernel<true, false>), grid, block, smem, st, a);
     else if (h->pow2) hipLaunchKernelGGL((scan_kernel<false, true>), grid, block, smem, st, a);
@@ -394,10 +405,10 @@ static int run_step(f110_handle *h, const double *actions, int reset_only, hipSt
     memset(&s, 0, sizeof(s));
     s.map = h->map; s.scan = scan_dev(h); s.n_cars = N; s.agents = c.num_agents;
     s.pose_src = b.state; s.pose_stride = 7; s.yaw_off = 4;
-    s.state = b.state; s.pose_snap = b.pose_snap; s.noise_step = b.noise_step;
+    s.state = b.state; s.noise_step = b.noise_step; s.beam_order = h->d_beam_order;
     s.noise = h->noise_T > 0 ? h->d_noise : nullptr; s.noise_T = h->noise_T > 0 ? h->noise_T : 1;
-    s.scan_angles = h->d_scan_angles; s.beam_cosines = h->d_beam_cosines; s.side_distances = h->d_side;
-    s.ttc_thresh = c.ttc_thresh; s.car_length = h->params.v[P_LENGTH]; s.car_width = h->params.v[P_WIDTH];
+    s.beam_cosines = h->d_beam_cosines; s.side_distances = h->d_side;
+    s.ttc_thresh = c.ttc_thresh;
     s.in_collision = b.in_collision; s.pending_reset = b.pending_reset; s.reset_only = reset_only;
     s.out_f32 = b.scans; s.out_f64 = b.scans_f64; s.lookups = b.lookups;
     const bool prof = h->prof_on && (size_t)(2 * h->prof_n + 1) < h->prof_ev.size();
@@ -515,7 +526,7 @@ extern "C" int f110_scan(f110_handle *h, const double *poses, int32_t n, double 
     memset(&s, 0, sizeof(s));
     s.map = h->map; s.scan = scan_dev(h); s.n_cars = n; s.agents = 1;
     s.pose_src = poses; s.pose_stride = 3; s.yaw_off = 2;
-    s.out_f32 = out32; s.out_f64 = out64; s.lookups = lookups; s.noise_T = 1;
+    s.out_f32 = out32; s.out_f64 = out64; s.lookups = lookups; s.noise_T = 1; s.beam_order = h->d_beam_order;
     return launch_scan(h, s, (hipStream_t)stream);
 }
 

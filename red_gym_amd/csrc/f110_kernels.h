@@ -10,16 +10,19 @@
 
 namespace f110 {
 
+// wave-wide vote straight on the condition mask (HIP's __ballot round-trips through a VGPR)
+__device__ inline unsigned long long vote(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 constexpr int WAVE = 64;
 #ifndef F110_SCAN_WAVES
-#define F110_SCAN_WAVES 8
+#define F110_SCAN_WAVES 4
 #endif
 #ifndef F110_REFILL_MIN_IDLE
-#define F110_REFILL_MIN_IDLE 16
+#define F110_REFILL_MIN_IDLE 24
 #endif
 constexpr int SCAN_WAVES = F110_SCAN_WAVES;   // cars per workgroup (one wavefront each)
 constexpr int SCAN_THREADS = SCAN_WAVES * WAVE;
-constexpr int LUT_LDS = 1024;                 // distance LUT entries staged in LDS (d2 < 1024)
+constexpr int LUT_LDS = 1024;                 // distance LUT entries staged in LDS (d2 < 1024), 8 KiB
 constexpr int CODE_ESC = 65535;               // cell code: read the fp64 table instead
 constexpr int REFILL_MIN_IDLE = F110_REFILL_MIN_IDLE; // refill the wave's beam slots once this many lanes idle
 
@@ -38,39 +41,48 @@ struct ScanDev {
     const double *sines, *cosines;   // [theta_dis] (laser_models.py:379-381)
 };
 
-// laser_models.py:56-104: (x, y) -> distance-table value.  IDENT: origin yaw == 0
-// (c=1, s=0: the rotation is the identity in exact arithmetic).  POW2: resolution
-// is a power of two, so multiplying by 1/res equals the reference's division.
+// laser_models.py:56-104: (x, y) -> distance-table value, branch-free.  IDENT: origin
+// yaw == 0 (c=1, s=0: the rotation is the identity in exact arithmetic).  POW2:
+// resolution is a power of two, so multiplying by 1/res equals the reference's
+// division.  Lanes with `live == false` execute too (no exec-mask juggling in the march
+// loop) but read LUT entry 0 and return 0.0, which parks their ray.
 template <bool IDENT, bool POW2>
-__device__ inline double dist_lookup(const MapDev &m, const double *lds_lut, double x, double y)
+__device__ inline double dist_lookup(const MapDev &m, const double *lds_lut, double x, double y, bool live)
 {
-    double xt = x - m.ox, yt = y - m.oy;
+    const double xt = x - m.ox, yt = y - m.oy;
     double xr, yr;
     if (IDENT) { xr = xt; yr = yt; }
     else { xr = xt * m.oc + yt * m.os; yr = -xt * m.os + yt * m.oc; }
-    // negated >= also sends NaN to the out-of-bounds value instead of a wild index
-    bool oob = !(xr >= 0) || (xr >= m.wres) || !(yr >= 0) || (yr >= m.hres);
-    double qx = xr * m.rinv, qy = yr * m.rinv;
+    // bitwise (not short-circuit) so that no branch is formed; the negated >= also sends
+    // NaN to the out-of-bounds value instead of a wild index
+    const bool oob = (!(xr >= 0)) | (xr >= m.wres) | (!(yr >= 0)) | (yr >= m.hres);
+    const double qx = xr * m.rinv, qy = yr * m.rinv;
     int ci = (int)qx, ri = (int)qy;
     if (!POW2) {
         // int(x_rot/resolution) needs the IEEE quotient: q*rinv is within ~2e-12 of it,
         // so only quotients within 1e-9 of an integer take the true division.
-        double fx = qx - (double)ci, fy = qy - (double)ri;
-        if (fx < 1e-9 || fx > 1. - 1e-9) ci = (int)(xr / m.res);
-        if (fy < 1e-9 || fy > 1. - 1e-9) ri = (int)(yr / m.res);
+        const double fx = qx - (double)ci, fy = qy - (double)ri;
+        const bool near_int = (fx < 1e-9) | (fx > 1. - 1e-9) | (fy < 1e-9) | (fy > 1. - 1e-9);
+        if (__builtin_expect(vote(near_int & live) != 0ull, 0)) {
+            if (near_int) { ci = (int)(xr / m.res); ri = (int)(yr / m.res); }
+        }
     }
-    ci = ci < 0 ? 0 : (ci > m.W - 1 ? m.W - 1 : ci);
-    ri = ri < 0 ? 0 : (ri > m.H - 1 ? m.H - 1 : ri);
-    int idx = oob ? 0 : ri * m.W + ci;
-    const unsigned code = m.cells[idx];
+    ci = min(max(ci, 0), m.W - 1); // v_med3_i32; also keeps out-of-bounds / idle lanes on valid memory
+    ri = min(max(ri, 0), m.H - 1);
+    const unsigned idx = (unsigned)ri * (unsigned)m.W + (unsigned)ci;
+    const unsigned code = *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(m.cells) + (size_t)(idx * 2u));
+    const bool use = live & !oob;
     // common case (d2 < LUT_LDS, i.e. within ~2 m of a wall): one ds_read_b64
-    double d = lds_lut[code < (unsigned)LUT_LDS ? code : 0u];
+    const unsigned lc = use ? min(code, (unsigned)(LUT_LDS - 1)) : 0u;
+    double d = lds_lut[lc];
     // pin the LDS read: otherwise the compiler folds it and the rare global reads below
     // into one flat_load through a selected generic pointer
     asm volatile("" : "+v"(d));
-    if (__builtin_expect(code >= (unsigned)LUT_LDS, 0))
-        d = (code != (unsigned)CODE_ESC) ? m.lut[code] : m.dt[idx];
-    return oob ? m.oob : d;
+    const bool far = use & (code >= (unsigned)LUT_LDS);
+    if (__builtin_expect(vote(far) != 0ull, 0)) {
+        if (far) d = (code != (unsigned)CODE_ESC) ? m.lut[code] : m.dt[idx];
+    }
+    return (oob & live) ? m.oob : d;
 }
 
 // laser_models.py:167-184: LUT index of beam b.  The reference advances
@@ -84,7 +96,7 @@ __device__ inline int beam_theta_index(double t0w, int b, const ScanDev &s)
     t -= floor(t * s.inv_td) * td; // any error lands in the guard band below
     int idx = (int)t;
     double fr = t - (double)idx;
-    if (!(fr > 1e-8 && fr < 1. - 1e-8) || idx < 0 || idx >= s.theta_dis) {
+    if (__builtin_expect(!(fr > 1e-8 && fr < 1. - 1e-8) || idx < 0 || idx >= s.theta_dis, 0)) {
         double tt = t0w;
         for (int j = 0; j < b; j++) {
             tt += s.inc;
@@ -105,150 +117,139 @@ struct ScanArgs {
     int pose_stride, yaw_off;
     // full-step extras (all NULL for the function-level scan)
     double *state;               // [N,7]: read vel, zero state[3:] on iTTC hit
-    const double *pose_snap;     // [N,3]: opponents' poses
     int32_t *noise_step;         // [N]
     const double *noise;         // [T,nb] or NULL
     long long noise_T;
-    const double *scan_angles, *beam_cosines, *side_distances; // [nb]
-    double ttc_thresh, car_length, car_width;
+    const double *beam_cosines, *side_distances; // [nb]
+    double ttc_thresh;
     uint8_t *in_collision;       // [N]
     const uint8_t *pending_reset;// [B]
     int reset_only;              // 1: only envs with pending_reset are processed
+    const uint16_t *beam_order;  // [nb] permutation: k-th beam to be marched (long rays first)
     // outputs
     float *out_f32;              // [N,nb] or NULL
     double *out_f64;             // [N,nb] or NULL
-    uint32_t *lookups;           // [N] or NULL
+    uint32_t *lookups;           // [N] or NULL (accumulated)
 };
 
+// One wavefront per car.  Lanes own rays; a finished ray parks its lane (the lookup
+// returns 0.0 for it) until at least REFILL_MIN_IDLE lanes are idle, then every idle
+// lane (a) finishes its previous beam -- noise, iTTC candidate test, fp32/fp64 store --
+// and (b) takes the next beam of the car.  No LDS staging of the scan: the only LDS
+// use is the 8 KiB distance LUT shared by the workgroup, so occupancy is register-bound.
 template <bool IDENT, bool POW2>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double *s_lut = reinterpret_cast<double *>(smem);
-    const int nb = a.scan.nb;
-    const int nb_pad = (nb + 1) & ~1;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    double *s_res = s_lut + LUT_LDS + wave * nb_pad;
-
+    __shared__ double s_lut[LUT_LDS];
     for (int i = threadIdx.x; i < LUT_LDS; i += SCAN_THREADS) s_lut[i] = a.map.lut[i];
     __syncthreads();
 
-    const int car = blockIdx.x * SCAN_WAVES + wave;
+    const int nb = a.scan.nb;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int car = blockIdx.x * SCAN_WAVES + wave; // wave-uniform (scalar)
     if (car >= a.n_cars) return;
-    const int env = car / a.agents;
-    if (a.reset_only && !a.pending_reset[env]) return;
+    if (a.reset_only && !a.pending_reset[car / a.agents]) return;
 
     const double px = a.pose_src[(size_t)car * a.pose_stride];
     const double py = a.pose_src[(size_t)car * a.pose_stride + 1];
     const double yaw = a.pose_src[(size_t)car * a.pose_stride + a.yaw_off];
     const double eps = a.scan.eps, max_range = a.scan.max_range;
 
+    // per-car constants of the finishing stage
+    double *st = a.state ? a.state + (size_t)car * 7 : nullptr;
+    const double vel = st ? st[3] : 0.0;
+    const bool do_ttc = st && vel != 0.0;                 // laser_models.py:206
+    // iTTC hit needs 0 <= (v - side)/(vel*cos) < thresh, hence |v - side| < thresh*|vel|:
+    // only such candidate beams pay the exact fp64 division
+    const double cand = a.ttc_thresh * fabs(vel) * 1.000000001;
+    const double *nz = nullptr;
+    if (st && a.noise) nz = a.noise + (size_t)((long long)a.noise_step[car] % a.noise_T) * nb;
+    float *o32 = a.out_f32 ? a.out_f32 + (size_t)car * nb : nullptr;
+    double *o64 = a.out_f64 ? a.out_f64 + (size_t)car * nb : nullptr;
+    bool hit = false;
+
+    // finishing stage of one beam: clamp (laser_models.py:143-144), noise (:450-452),
+    // stores, iTTC (:189-217)
+    auto emit = [&](int i, double tot) {
+        double v = tot > max_range ? max_range : tot;
+        if (nz) v += nz[i];
+        if (o32) o32[i] = (float)v;
+        if (o64) o64[i] = v;
+        if (do_ttc) {
+            const double sd = v - a.side_distances[i];
+            if (__builtin_expect(fabs(sd) < cand, 0)) {
+                const double proj_vel = vel * a.beam_cosines[i];
+                const double ttc = sd / proj_vel;
+                if ((ttc < a.ttc_thresh) && (ttc >= 0.0)) hit = true;
+            }
+        }
+    };
+
     // ---- ray march (laser_models.py:107-186) -------------------------------------
     // The first table read of every beam is at the car itself (:129): done once.
-    const double d0 = dist_lookup<IDENT, POW2>(a.map, s_lut, px, py);
-    unsigned nlook = 0;
+    const double d0 = dist_lookup<IDENT, POW2>(a.map, s_lut, px, py, true);
+    unsigned nlook = (unsigned)nb; // the reference reads the table once per beam before marching
     if (!(d0 > eps && d0 <= max_range)) {
-        const double v = d0 > max_range ? max_range : d0;
-        for (int i = lane; i < nb; i += WAVE) s_res[i] = v;
+        for (int i = lane; i < nb; i += WAVE) emit(i, d0);
     } else {
         const double td = (double)a.scan.theta_dis;
         double t0w = td * (yaw - a.scan.fov / 2.) / (2. * F110_PI);
         t0w = fmod(t0w, td);
         while (t0w < 0) t0w += td;
 
-        int next = 0;           // wave-uniform: next unassigned beam
+        int next = 0;           // wave-uniform: next unassigned slot of beam_order
         bool active = false;
-        int beam = 0;
-        double x = 0, y = 0, c = 0, s = 0, total = 0;
+        int beam = -1;          // beam whose result `total` holds (-1: none)
+        double x = px, y = py, c = 0, s = 0, total = 0;
         for (;;) {
-            // ---- refill phase: every idle lane takes the next unassigned beam ----
-            const unsigned long long idle = __ballot(!active);
+            // ---- refill phase: idle lanes finish their beam and take the next one ----
+            const unsigned long long idle = vote(!active);
             const int nidle = __popcll(idle);
-            if (next < nb) {
-                if (!active) {
-                    const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32),
-                                        __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
-                    const int b = next + rank;
-                    if (b < nb) {
-                        const int ti = beam_theta_index(t0w, b, a.scan);
-                        s = a.scan.sines[ti];
-                        c = a.scan.cosines[ti];
-                        x = px + d0 * c;
-                        y = py + d0 * s;
-                        total = d0;
-                        beam = b;
-                        active = true;
-                    }
+            if (!active) {
+                if (beam >= 0) emit(beam, total);
+                beam = -1;
+                const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32),
+                                    __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
+                const int k = next + rank;
+                if (k < nb) {
+                    const int b = a.beam_order[k];
+                    const int ti = beam_theta_index(t0w, b, a.scan);
+                    s = a.scan.sines[ti];
+                    c = a.scan.cosines[ti];
+                    x = px + d0 * c;
+                    y = py + d0 * s;
+                    total = d0;
+                    beam = b;
+                    active = true;
                 }
-                next += nidle;
-            } else if (nidle == WAVE) {
-                break;
             }
-            // ---- march phase: step all active rays until enough lanes are idle again
-            // (or, once no beams are left, until the wave has drained) ----
-            const int stop = next < nb ? REFILL_MIN_IDLE : WAVE;
-            int idle_now;
+            next += nidle;
+            int nact = __popcll(vote(active));
+            if (nact == 0) break;
+            // ---- march phase: every lane steps (idle lanes are parked by d = 0) until
+            // enough lanes are idle again or, once no beams are left, the wave has drained ----
+            const int go = next < nb ? WAVE - REFILL_MIN_IDLE : 0; // keep marching while nact > go
             do {
-                if (active) {
-                    const double d = dist_lookup<IDENT, POW2>(a.map, s_lut, x, y);
-                    nlook++;
-                    total += d;
-                    if (d > eps && total <= max_range) {
-                        x += d * c;
-                        y += d * s;
-                    } else {
-                        s_res[beam] = total > max_range ? max_range : total;
-                        active = false;
-                    }
-                }
-                idle_now = __popcll(__ballot(!active));
-            } while (idle_now < stop);
+                nlook += (unsigned)nact;
+                const double d = dist_lookup<IDENT, POW2>(a.map, s_lut, x, y, active);
+                total += d;
+                x += d * c;
+                y += d * s;
+                active = (d > eps) & (total <= max_range);
+                nact = __popcll(vote(active));
+            } while (nact > go);
         }
     }
-    if (a.lookups) {
-        // the reference reads the table once per beam before marching
-        unsigned tot = nlook;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
-        if (lane == 0) a.lookups[car] += tot + (unsigned)nb;
-    }
+    if (a.lookups && lane == 0) a.lookups[car] += nlook;
 
-    // ---- noise + iTTC (laser_models.py:450-452, :189-217; base_classes.py:227-252) ----
-    if (a.state) {
-        double *st = a.state + (size_t)car * 7;
-        const double vel = st[3];
-        const double *nz = nullptr;
-        if (a.noise) {
-            const long long row = (long long)a.noise_step[car] % a.noise_T;
-            nz = a.noise + (size_t)row * nb;
-        }
-        bool hit = false;
-        for (int i = lane; i < nb; i += WAVE) {
-            double v = s_res[i];
-            if (nz) v += nz[i];
-            if (vel != 0.0) {
-                const double proj_vel = vel * a.beam_cosines[i];
-                const double ttc = (v - a.side_distances[i]) / proj_vel;
-                if ((ttc < a.ttc_thresh) && (ttc >= 0.0)) hit = true;
-            }
-            s_res[i] = v;
-        }
-        const bool any_hit = __ballot(hit) != 0ull;
+    // ---- iTTC result (base_classes.py:241-250) ------------------------------------
+    if (st) {
+        const bool any_hit = vote(hit) != 0ull;
         if (lane == 0) {
             if (any_hit) { st[3] = 0.; st[4] = 0.; st[5] = 0.; st[6] = 0.; }
             a.in_collision[car] = any_hit ? 1 : 0;
             a.noise_step[car] += 1;
         }
-    }
-
-    // ---- coalesced write-out -------------------------------------------------------
-    if (a.out_f32) {
-        float *o = a.out_f32 + (size_t)car * nb;
-        for (int i = lane; i < nb; i += WAVE) o[i] = (float)s_res[i];
-    }
-    if (a.out_f64) {
-        double *o = a.out_f64 + (size_t)car * nb;
-        for (int i = lane; i < nb; i += WAVE) o[i] = s_res[i];
     }
 }
 
