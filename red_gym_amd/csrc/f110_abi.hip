@@ -163,15 +163,25 @@ static int upload(double **dst, const double *src, size_t n)
     return F110_OK;
 }
 
-// Order in which a car's beams are handed to idle lanes.  Rays along the car's
-// longitudinal axis run down the track and need the most march steps, so they start
-// first and the short side rays fill the tail: beams sorted by |sin(angle)|, ties by index.
+// Order in which a car's beams are handed to idle lanes: chunks of 64 angularly
+// adjacent beams (adjacent rays sample neighbouring cells, which keeps a wave's gathers
+// on few cache lines), the chunks sorted so that rays along the car's longitudinal axis
+// -- they run down the track and need the most march steps -- start first and the short
+// side rays fill the tail (key: |sin| of the chunk's centre angle).
+#ifndef F110_ORDER_CHUNK
+#define F110_ORDER_CHUNK 64
+#endif
 static int set_beam_order(f110_handle *h)
 {
     const int nb = h->cfg.num_beams;
     const double incr = h->cfg.fov / (nb - 1);
+    const int chunk = F110_ORDER_CHUNK;
     std::vector<std::pair<double, int>> key(nb);
-    for (int i = 0; i < nb; i++) key[i] = {std::fabs(std::sin(-h->cfg.fov / 2. + i * incr)), i};
+    for (int i = 0; i < nb; i++) {
+        const int c0 = (i / chunk) * chunk, c1 = std::min(nb - 1, c0 + chunk - 1);
+        const double centre = -h->cfg.fov / 2. + 0.5 * (c0 + c1) * incr;
+        key[i] = {std::fabs(std::sin(centre)) + 1e-9 * c0, i}; // chunks stay contiguous, beams in natural order
+    }
     std::sort(key.begin(), key.end());
     std::vector<uint16_t> order(nb);
     for (int i = 0; i < nb; i++) order[i] = (uint16_t)key[i].second;
@@ -261,7 +271,9 @@ static int install_map(f110_handle *h, const double *dt, const uint32_t *d2_or_n
                        double ox, double oy, double oc, double os)
 {
     const size_t n = (size_t)H * W;
-    std::vector<uint16_t> cells(n);
+    const int tpr = (W + 7) >> 3, tpc = (H + 7) >> 3;
+    const size_t n_tiled = (size_t)tpr * tpc * 64;
+    std::vector<uint16_t> cells(n_tiled, 0);
     for (size_t i = 0; i < n; i++) {
         uint64_t d2;
         if (d2_or_null) d2 = d2_or_null[i];
@@ -271,7 +283,9 @@ static int install_map(f110_handle *h, const double *dt, const uint32_t *d2_or_n
             d2 = (r >= 0 && r < 4.0e18) ? (uint64_t)r : (uint64_t)CODE_ESC;
             if (d2 < (uint64_t)CODE_ESC && res * std::sqrt((double)d2) != dt[i]) d2 = CODE_ESC;
         }
-        cells[i] = (uint16_t)(d2 < (uint64_t)CODE_ESC ? d2 : CODE_ESC);
+        const size_t r = i / W, c = i % W;
+        const size_t t = (((r >> 3) * tpr + (c >> 3)) << 6) | ((r & 7) << 3) | (c & 7);
+        cells[t] = (uint16_t)(d2 < (uint64_t)CODE_ESC ? d2 : CODE_ESC);
     }
     std::vector<double> lut(CODE_ESC);
     for (int i = 0; i < CODE_ESC; i++) lut[i] = res * std::sqrt((double)i);
@@ -279,15 +293,15 @@ static int install_map(f110_handle *h, const double *dt, const uint32_t *d2_or_n
     HIP_TRY(hipDeviceSynchronize()); // the previous map may still be in use by enqueued steps
     if (h->d_cells) { (void)hipFree(h->d_cells); h->d_cells = nullptr; }
     if (h->d_dt) { (void)hipFree(h->d_dt); h->d_dt = nullptr; }
-    HIP_TRY(hipMalloc((void **)&h->d_cells, n * sizeof(uint16_t)));
+    HIP_TRY(hipMalloc((void **)&h->d_cells, n_tiled * sizeof(uint16_t)));
     HIP_TRY(hipMalloc((void **)&h->d_dt, n * sizeof(double)));
-    HIP_TRY(hipMemcpy(h->d_cells, cells.data(), n * sizeof(uint16_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->d_cells, cells.data(), n_tiled * sizeof(uint16_t), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->d_dt, dt, n * sizeof(double), hipMemcpyHostToDevice));
     int rc = upload(&h->d_lut, lut.data(), lut.size());
     if (rc) return rc;
     MapDev &m = h->map;
     m.cells = h->d_cells; m.lut = h->d_lut; m.dt = h->d_dt;
-    m.H = H; m.W = W; m.res = res; m.rinv = 1.0 / res;
+    m.H = H; m.W = W; m.tiles_per_row = tpr; m.res = res; m.rinv = 1.0 / res;
     m.ox = ox; m.oy = oy; m.oc = oc; m.os = os;
     m.wres = W * res; // width * resolution (laser_models.py:79)
     m.hres = H * res;

@@ -18,7 +18,7 @@ constexpr int WAVE = 64;
 #define F110_SCAN_WAVES 4
 #endif
 #ifndef F110_REFILL_MIN_IDLE
-#define F110_REFILL_MIN_IDLE 24
+#define F110_REFILL_MIN_IDLE 32
 #endif
 constexpr int SCAN_WAVES = F110_SCAN_WAVES;   // cars per workgroup (one wavefront each)
 constexpr int SCAN_THREADS = SCAN_WAVES * WAVE;
@@ -26,8 +26,15 @@ constexpr int LUT_LDS = 1024;                 // distance LUT entries staged in 
 constexpr int CODE_ESC = 65535;               // cell code: read the fp64 table instead
 constexpr int REFILL_MIN_IDLE = F110_REFILL_MIN_IDLE; // refill the wave's beam slots once this many lanes idle
 
+// The u16 cell table is stored in 8x8-cell tiles (128 B = one cache line): the 64 rays
+// of a wave sample neighbouring points, so a gather touches a few lines instead of one
+// line per lane (a row-major layout measured ~40 distinct lines per 64-lane gather and
+// made the kernel L1-tag-rate bound).
+constexpr int TILE_SHIFT = 3; // 8x8 cells
+
 struct MapDev {
-    const uint16_t *cells;  // [H*W] min(d2, 65535); 65535 = escape to dt
+    const uint16_t *cells;  // tiled [ceil(H/8)*ceil(W/8)][8][8] min(d2, 65535); 65535 = escape to dt
+    int tiles_per_row;      // ceil(W/8)
     const double *lut;      // [65535] resolution*sqrt(d2)
     const double *dt;       // [H*W] exact fp64 distance table (escape path, rarely touched)
     int H, W;
@@ -69,8 +76,11 @@ __device__ inline double dist_lookup(const MapDev &m, const double *lds_lut, dou
     }
     ci = min(max(ci, 0), m.W - 1); // v_med3_i32; also keeps out-of-bounds / idle lanes on valid memory
     ri = min(max(ri, 0), m.H - 1);
-    const unsigned idx = (unsigned)ri * (unsigned)m.W + (unsigned)ci;
-    const unsigned code = *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(m.cells) + (size_t)(idx * 2u));
+    const unsigned uri = (unsigned)ri, uci = (unsigned)ci;
+    unsigned tidx = (((uri >> TILE_SHIFT) * (unsigned)m.tiles_per_row + (uci >> TILE_SHIFT)) << (2 * TILE_SHIFT)) |
+                    ((uri & 7u) << TILE_SHIFT) | (uci & 7u);
+    tidx = live ? tidx : 0u; // parked lanes all read cell 0: no extra cache lines
+    const unsigned code = *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(m.cells) + (size_t)(tidx * 2u));
     const bool use = live & !oob;
     // common case (d2 < LUT_LDS, i.e. within ~2 m of a wall): one ds_read_b64
     const unsigned lc = use ? min(code, (unsigned)(LUT_LDS - 1)) : 0u;
@@ -80,7 +90,7 @@ __device__ inline double dist_lookup(const MapDev &m, const double *lds_lut, dou
     asm volatile("" : "+v"(d));
     const bool far = use & (code >= (unsigned)LUT_LDS);
     if (__builtin_expect(vote(far) != 0ull, 0)) {
-        if (far) d = (code != (unsigned)CODE_ESC) ? m.lut[code] : m.dt[idx];
+        if (far) d = (code != (unsigned)CODE_ESC) ? m.lut[code] : m.dt[(size_t)uri * (unsigned)m.W + uci];
     }
     return (oob & live) ? m.oob : d;
 }
