@@ -40,9 +40,11 @@ struct f110_handle {
     bool has_map = false, bound = false;
     f110_buffers bufs;
     // device tables owned by the handle
-    double *d_sines = nullptr, *d_cosines = nullptr;
     double *d_scan_angles = nullptr, *d_beam_cosines = nullptr, *d_side = nullptr;
-    uint16_t *d_cells = nullptr, *d_beam_order = nullptr;
+    uint16_t *d_cells = nullptr, *d_chunk0 = nullptr;
+    double2 *d_cs = nullptr;          // interleaved {cos, sin} LUT
+    double *d_zero_row = nullptr;     // noise row used when noise is off
+    std::vector<double> h_sines, h_cosines;
     double *d_lut = nullptr, *d_dt = nullptr;
     double *d_noise = nullptr;
     long long noise_T = 0;
@@ -167,26 +169,35 @@ static int upload(double **dst, const double *src, size_t n)
 // adjacent beams (adjacent rays sample neighbouring cells, which keeps a wave's gathers
 // on few cache lines), the chunks sorted so that rays along the car's longitudinal axis
 // -- they run down the track and need the most march steps -- start first and the short
-// side rays fill the tail (key: |sin| of the chunk's centre angle).
-#ifndef F110_ORDER_CHUNK
-#define F110_ORDER_CHUNK 64
-#endif
+// side rays fill the tail (key: |sin| of the chunk's centre angle).  A trailing partial
+// chunk goes last so that slot k maps to beam chunk0[k >> 6] + (k & 63).
 static int set_beam_order(f110_handle *h)
 {
     const int nb = h->cfg.num_beams;
     const double incr = h->cfg.fov / (nb - 1);
-    const int chunk = F110_ORDER_CHUNK;
-    std::vector<std::pair<double, int>> key(nb);
-    for (int i = 0; i < nb; i++) {
-        const int c0 = (i / chunk) * chunk, c1 = std::min(nb - 1, c0 + chunk - 1);
-        const double centre = -h->cfg.fov / 2. + 0.5 * (c0 + c1) * incr;
-        key[i] = {std::fabs(std::sin(centre)) + 1e-9 * c0, i}; // chunks stay contiguous, beams in natural order
+    const int nchunks = (nb + 63) / 64, nfull = nb / 64;
+    std::vector<std::pair<double, int>> key;
+    for (int c = 0; c < nfull; c++) {
+        const double centre = -h->cfg.fov / 2. + (64 * c + 31.5) * incr;
+        key.push_back({std::fabs(std::sin(centre)), 64 * c});
     }
     std::sort(key.begin(), key.end());
-    std::vector<uint16_t> order(nb);
-    for (int i = 0; i < nb; i++) order[i] = (uint16_t)key[i].second;
-    if (!h->d_beam_order) HIP_TRY(hipMalloc((void **)&h->d_beam_order, nb * sizeof(uint16_t)));
-    HIP_TRY(hipMemcpy(h->d_beam_order, order.data(), nb * sizeof(uint16_t), hipMemcpyHostToDevice));
+    std::vector<uint16_t> chunk0;
+    for (auto &k : key) chunk0.push_back((uint16_t)k.second);
+    if (nchunks > nfull) chunk0.push_back((uint16_t)(64 * nfull));
+    if (!h->d_chunk0) HIP_TRY(hipMalloc((void **)&h->d_chunk0, MAX_CHUNKS * sizeof(uint16_t)));
+    HIP_TRY(hipMemcpy(h->d_chunk0, chunk0.data(), chunk0.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    return F110_OK;
+}
+
+// (Re)builds the interleaved {cos, sin} device table from the host copies.
+static int upload_cs(f110_handle *h)
+{
+    const int n = h->cfg.theta_dis;
+    std::vector<double2> cs(n);
+    for (int i = 0; i < n; i++) { cs[i].x = h->h_cosines[i]; cs[i].y = h->h_sines[i]; }
+    if (!h->d_cs) HIP_TRY(hipMalloc((void **)&h->d_cs, n * sizeof(double2)));
+    HIP_TRY(hipMemcpy(h->d_cs, cs.data(), n * sizeof(double2), hipMemcpyHostToDevice));
     return F110_OK;
 }
 
@@ -196,8 +207,8 @@ extern "C" int f110_create(const f110_config *cfg, f110_handle **out)
     if (cfg->num_envs < 1 || cfg->num_agents < 1 || cfg->num_agents > F110_MAX_AGENTS)
         return fail(F110_E_INVALID, "f110_create: num_envs=%d num_agents=%d out of range (agents 1..%d)",
                     cfg->num_envs, cfg->num_agents, F110_MAX_AGENTS);
-    if (cfg->num_beams < 2 || cfg->num_beams > 2048 || cfg->theta_dis < 2)
-        return fail(F110_E_INVALID, "f110_create: num_beams=%d (2..2048) theta_dis=%d", cfg->num_beams, cfg->theta_dis);
+    if (cfg->num_beams < 2 || cfg->num_beams > 4096 || cfg->theta_dis < 2)
+        return fail(F110_E_INVALID, "f110_create: num_beams=%d (2..4096) theta_dis=%d", cfg->num_beams, cfg->theta_dis);
     if (cfg->integrator != F110_RK4 && cfg->integrator != F110_EULER)
         return fail(F110_E_INVALID, "f110_create: invalid integrator %d (RK4=1, Euler=2)", cfg->integrator);
     if (cfg->ego_idx < 0 || cfg->ego_idx >= cfg->num_agents)
@@ -219,7 +230,10 @@ extern "C" int f110_create(const f110_config *cfg, f110_handle **out)
     std::vector<double> s, c, ang, bcos, side;
     default_tables(*cfg, s, c, ang, bcos, side);
     int rc;
-    if ((rc = upload(&h->d_sines, s.data(), s.size())) || (rc = upload(&h->d_cosines, c.data(), c.size())) ||
+    h->h_sines = s;
+    h->h_cosines = c;
+    std::vector<double> zeros(cfg->num_beams, 0.0);
+    if ((rc = upload_cs(h)) || (rc = upload(&h->d_zero_row, zeros.data(), zeros.size())) ||
         (rc = upload(&h->d_scan_angles, ang.data(), ang.size())) ||
         (rc = upload(&h->d_beam_cosines, bcos.data(), bcos.size())) ||
         (rc = upload(&h->d_side, side.data(), side.size())) || (rc = set_beam_order(h))) {
@@ -234,8 +248,8 @@ extern "C" void f110_destroy(f110_handle *h)
 {
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
-    void *ptrs[] = {h->d_sines, h->d_cosines, h->d_scan_angles, h->d_beam_cosines, h->d_side,
-                    h->d_cells, h->d_lut, h->d_dt, h->d_noise, h->d_beam_order};
+    void *ptrs[] = {h->d_cs, h->d_zero_row, h->d_scan_angles, h->d_beam_cosines, h->d_side,
+                    h->d_cells, h->d_lut, h->d_dt, h->d_noise, h->d_chunk0};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
@@ -256,8 +270,9 @@ extern "C" int f110_set_tables(f110_handle *h, const double *sines, const double
     if (!h) return fail(F110_E_INVALID, "f110_set_tables: null handle");
     HIP_TRY(hipSetDevice(h->cfg.device));
     int rc = F110_OK;
-    if (sines && (rc = upload(&h->d_sines, sines, h->cfg.theta_dis))) return rc;
-    if (cosines && (rc = upload(&h->d_cosines, cosines, h->cfg.theta_dis))) return rc;
+    if (sines) h->h_sines.assign(sines, sines + h->cfg.theta_dis);
+    if (cosines) h->h_cosines.assign(cosines, cosines + h->cfg.theta_dis);
+    if ((sines || cosines) && (rc = upload_cs(h))) return rc;
     if (ang && (rc = upload(&h->d_scan_angles, ang, h->cfg.num_beams))) return rc;
     if (bcos && (rc = upload(&h->d_beam_cosines, bcos, h->cfg.num_beams))) return rc;
     if (side && (rc = upload(&h->d_side, side, h->cfg.num_beams))) return rc;
@@ -271,8 +286,8 @@ static int install_map(f110_handle *h, const double *dt, const uint32_t *d2_or_n
                        double ox, double oy, double oc, double os)
 {
     const size_t n = (size_t)H * W;
-    const int tpr = (W + 7) >> 3, tpc = (H + 7) >> 3;
-    const size_t n_tiled = (size_t)tpr * tpc * 64;
+    const int strips = (W + 7) >> 3, Hp = ((H + 7) >> 3) << 3;
+    const size_t n_tiled = (size_t)strips * Hp * 8;
     std::vector<uint16_t> cells(n_tiled, 0);
     for (size_t i = 0; i < n; i++) {
         uint64_t d2;
@@ -284,7 +299,7 @@ static int install_map(f110_handle *h, const double *dt, const uint32_t *d2_or_n
             if (d2 < (uint64_t)CODE_ESC && res * std::sqrt((double)d2) != dt[i]) d2 = CODE_ESC;
         }
         const size_t r = i / W, c = i % W;
-        const size_t t = (((r >> 3) * tpr + (c >> 3)) << 6) | ((r & 7) << 3) | (c & 7);
+        const size_t t = ((c >> 3) * (size_t)Hp + r) * 8 + (c & 7); // strip layout, see MapDev
         cells[t] = (uint16_t)(d2 < (uint64_t)CODE_ESC ? d2 : CODE_ESC);
     }
     std::vector<double> lut(CODE_ESC);
@@ -301,7 +316,7 @@ static int install_map(f110_handle *h, const double *dt, const uint32_t *d2_or_n
     if (rc) return rc;
     MapDev &m = h->map;
     m.cells = h->d_cells; m.lut = h->d_lut; m.dt = h->d_dt;
-    m.H = H; m.W = W; m.tiles_per_row = tpr; m.res = res; m.rinv = 1.0 / res;
+    m.H = H; m.W = W; m.strip_bytes = (unsigned)Hp * 16u; m.cells_bytes = (unsigned)(n_tiled * sizeof(uint16_t)); m.res = res; m.rinv = 1.0 / res;
     m.ox = ox; m.oy = oy; m.oc = oc; m.os = os;
     m.wres = W * res; // width * resolution (laser_models.py:79)
     m.hres = H * res;
@@ -316,7 +331,7 @@ static int install_map(f110_handle *h, const double *dt, const uint32_t *d2_or_n
 static int check_map_args(f110_handle *h, const void *p, int H, int W, double res, const char *who)
 {
     if (!h || !p) return fail(F110_E_INVALID, "%s: null argument", who);
-    if (H < 1 || W < 1 || (int64_t)H * W > (int64_t)1 << 30) return fail(F110_E_INVALID, "%s: bad map size %dx%d", who, H, W);
+    if (H < 1 || W < 1 || (int64_t)(H + 8) * (W + 8) > (int64_t)1 << 30) return fail(F110_E_INVALID, "%s: bad map size %dx%d", who, H, W);
     if (!(res > 0) || !std::isfinite(res)) return fail(F110_E_INVALID, "%s: bad resolution %g", who, res);
     return F110_OK;
 }
@@ -386,20 +401,25 @@ static ScanDev scan_dev(const f110_handle *h)
 {
     ScanDev s;
     s.nb = h->cfg.num_beams; s.theta_dis = h->cfg.theta_dis; s.fov = h->cfg.fov; s.eps = h->cfg.eps;
-    s.max_range = h->cfg.max_range; s.inc = h->theta_inc; s.inv_td = 1.0 / h->cfg.theta_dis; s.sines = h->d_sines; s.cosines = h->d_cosines;
+    s.max_range = h->cfg.max_range; s.inc = h->theta_inc; s.inv_td = 1.0 / h->cfg.theta_dis; s.cs = h->d_cs;
     return s;
+}
+
+template <bool STEP>
+static int launch_scan_t(f110_handle *h, const ScanArgs &a, hipStream_t st)
+{
+    const dim3 grid((a.n_cars + SCAN_WAVES - 1) / SCAN_WAVES), block(SCAN_THREADS);
+    if (h->ident && h->pow2) hipLaunchKernelGGL((scan_kernel<true, true, STEP>), grid, block, 0, st, a);
+    else if (h->ident) hipLaunchKernelGGL((scan_kernel<true, false, STEP>), grid, block, 0, st, a);
+    else if (h->pow2) hipLaunchKernelGGL((scan_kernel<false, true, STEP>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((scan_kernel<false, false, STEP>), grid, block, 0, st, a);
+    HIP_TRY(hipGetLastError());
+    return F110_OK;
 }
 
 static int launch_scan(f110_handle *h, const ScanArgs &a, hipStream_t st)
 {
-    const size_t smem = 0; // the LUT is static LDS
-    const dim3 grid((a.n_cars + SCAN_WAVES - 1) / SCAN_WAVES), block(SCAN_THREADS);
-    if (h->ident && h->pow2) hipLaunchKernelGGL((scan_kernel<true, true>), grid, block, smem, st, a);
-    else if (h->ident) hipLaunchKernelGGL((scan_kernel<true, false>), grid, block, smem, st, a);
-    else if (h->pow2) hipLaunchKernelGGL((scan_kernel<false, true>), grid, block, smem, st, a);
-    else hipLaunchKernelGGL((scan_kernel<false, false>), grid, block, smem, st, a);
-    HIP_TRY(hipGetLastError());
-    return F110_OK;
+    return a.state ? launch_scan_t<true>(h, a, st) : launch_scan_t<false>(h, a, st);
 }
 
 static int run_step(f110_handle *h, const double *actions, int reset_only, hipStream_t st)
@@ -419,8 +439,8 @@ static int run_step(f110_handle *h, const double *actions, int reset_only, hipSt
     memset(&s, 0, sizeof(s));
     s.map = h->map; s.scan = scan_dev(h); s.n_cars = N; s.agents = c.num_agents;
     s.pose_src = b.state; s.pose_stride = 7; s.yaw_off = 4;
-    s.state = b.state; s.noise_step = b.noise_step; s.beam_order = h->d_beam_order;
-    s.noise = h->noise_T > 0 ? h->d_noise : nullptr; s.noise_T = h->noise_T > 0 ? h->noise_T : 1;
+    s.state = b.state; s.noise_step = b.noise_step; s.chunk_beam0 = h->d_chunk0;
+    s.noise = h->noise_T > 0 ? h->d_noise : h->d_zero_row; s.noise_T = h->noise_T > 0 ? h->noise_T : 1;
     s.beam_cosines = h->d_beam_cosines; s.side_distances = h->d_side;
     s.ttc_thresh = c.ttc_thresh;
     s.in_collision = b.in_collision; s.pending_reset = b.pending_reset; s.reset_only = reset_only;
@@ -540,7 +560,7 @@ extern "C" int f110_scan(f110_handle *h, const double *poses, int32_t n, double 
     memset(&s, 0, sizeof(s));
     s.map = h->map; s.scan = scan_dev(h); s.n_cars = n; s.agents = 1;
     s.pose_src = poses; s.pose_stride = 3; s.yaw_off = 2;
-    s.out_f32 = out32; s.out_f64 = out64; s.lookups = lookups; s.noise_T = 1; s.beam_order = h->d_beam_order;
+    s.out_f32 = out32; s.out_f64 = out64; s.lookups = lookups; s.noise_T = 1; s.chunk_beam0 = h->d_chunk0;
     return launch_scan(h, s, (hipStream_t)stream);
 }
 

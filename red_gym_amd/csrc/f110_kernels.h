@@ -15,7 +15,7 @@ __device__ inline unsigned long long vote(bool p) { return __builtin_amdgcn_ball
 
 constexpr int WAVE = 64;
 #ifndef F110_SCAN_WAVES
-#define F110_SCAN_WAVES 4
+#define F110_SCAN_WAVES 2
 #endif
 #ifndef F110_REFILL_MIN_IDLE
 #define F110_REFILL_MIN_IDLE 32
@@ -26,73 +26,95 @@ constexpr int LUT_LDS = 1024;                 // distance LUT entries staged in 
 constexpr int CODE_ESC = 65535;               // cell code: read the fp64 table instead
 constexpr int REFILL_MIN_IDLE = F110_REFILL_MIN_IDLE; // refill the wave's beam slots once this many lanes idle
 
-// The u16 cell table is stored in 8x8-cell tiles (128 B = one cache line): the 64 rays
-// of a wave sample neighbouring points, so a gather touches a few lines instead of one
-// line per lane (a row-major layout measured ~40 distinct lines per 64-lane gather and
-// made the kernel L1-tag-rate bound).
-constexpr int TILE_SHIFT = 3; // 8x8 cells
-
+// The u16 cell table is stored in 8-column strips: cell (r, c) lives at
+// [c >> 3][r][c & 7], so one 128-B cache line holds an 8x8-cell block (rows 8k..8k+7 of
+// a strip).  The 64 rays of a wave sample neighbouring points, so a gather touches a
+// few lines instead of one line per lane (row-major measured ~40 distinct lines per
+// 64-lane gather and made the kernel L1-tag-rate bound), and the offset is one
+// multiply-add: (c >> 3) * strip_bytes + r * 16 + (c & 7) * 2.
 struct MapDev {
-    const uint16_t *cells;  // tiled [ceil(H/8)*ceil(W/8)][8][8] min(d2, 65535); 65535 = escape to dt
-    int tiles_per_row;      // ceil(W/8)
+    const uint16_t *cells;  // strips [ceil(W/8)][Hp][8] of min(d2, 65535); 65535 = escape to dt
+    unsigned cells_bytes;
+    unsigned strip_bytes;   // Hp * 16, Hp = H rounded up to a multiple of 8
     const double *lut;      // [65535] resolution*sqrt(d2)
     const double *dt;       // [H*W] exact fp64 distance table (escape path, rarely touched)
     int H, W;
     double res, rinv, ox, oy, oc, os, wres, hres, oob; // oob = dt[H-1][W-1] (laser_models.py:80-81,103)
 };
 
+// device-side view of MapDev with the cell table behind a buffer resource descriptor
+struct MapView {
+    __amdgpu_buffer_rsrc_t cells_rsrc;
+    unsigned strip_bytes;
+    const double *lut, *dt;
+    int H, W;
+    double res, rinv, ox, oy, oc, os, wres, hres;
+    __device__ void init(const MapDev &m)
+    {
+        strip_bytes = m.strip_bytes; lut = m.lut; dt = m.dt; H = m.H; W = m.W; res = m.res; rinv = m.rinv;
+        ox = m.ox; oy = m.oy; oc = m.oc; os = m.os; wres = m.wres; hres = m.hres;
+    }
+};
+
 struct ScanDev {
     int nb, theta_dis;
     double fov, eps, max_range, inc; // inc = theta_index_increment (laser_models.py:368)
     double inv_td;                   // 1 / theta_dis
-    const double *sines, *cosines;   // [theta_dis] (laser_models.py:379-381)
+    const double2 *cs;               // [theta_dis] {cos, sin} of the LUT angles (laser_models.py:379-381)
 };
 
 // laser_models.py:56-104: (x, y) -> distance-table value, branch-free.  IDENT: origin
 // yaw == 0 (c=1, s=0: the rotation is the identity in exact arithmetic).  POW2:
-// resolution is a power of two, so multiplying by 1/res equals the reference's
-// division.  Lanes with `live == false` execute too (no exec-mask juggling in the march
-// loop) but read LUT entry 0 and return 0.0, which parks their ray.
+// resolution is a power of two, so q = x_rot * (1/res) IS the reference's quotient and
+// "x_rot < 0 or x_rot >= width*res" (:79) is exactly "floor(q) outside [0, W)".
+// Lanes with `live == false` execute too (no exec-mask juggling in the march loop) but
+// read cell 0 / LUT entry 0 and return 0.0, which parks their ray.
 template <bool IDENT, bool POW2>
-__device__ inline double dist_lookup(const MapDev &m, const double *lds_lut, double x, double y, bool live)
+__device__ inline double dist_lookup(const MapView &m, const double *lds_lut, double x, double y, bool live)
 {
     const double xt = x - m.ox, yt = y - m.oy;
     double xr, yr;
     if (IDENT) { xr = xt; yr = yt; }
     else { xr = xt * m.oc + yt * m.os; yr = -xt * m.os + yt * m.oc; }
-    // bitwise (not short-circuit) so that no branch is formed; the negated >= also sends
-    // NaN to the out-of-bounds value instead of a wild index
-    const bool oob = (!(xr >= 0)) | (xr >= m.wres) | (!(yr >= 0)) | (yr >= m.hres);
     const double qx = xr * m.rinv, qy = yr * m.rinv;
-    int ci = (int)qx, ri = (int)qy;
+    const double fx = floor(qx), fy = floor(qy);
+    int ci = (int)fx, ri = (int)fy; // saturating; negative / huge values fail the range test below
     if (!POW2) {
-        // int(x_rot/resolution) needs the IEEE quotient: q*rinv is within ~2e-12 of it,
-        // so only quotients within 1e-9 of an integer take the true division.
-        const double fx = qx - (double)ci, fy = qy - (double)ri;
-        const bool near_int = (fx < 1e-9) | (fx > 1. - 1e-9) | (fy < 1e-9) | (fy > 1. - 1e-9);
-        if (__builtin_expect(vote(near_int & live) != 0ull, 0)) {
-            if (near_int) { ci = (int)(xr / m.res); ri = (int)(yr / m.res); }
+        // int(x_rot/resolution) and the bounds test need the IEEE quotient: x_rot*(1/res) is
+        // within ~2e-12 of it, so only quotients within 1e-9 of an integer (where truncation
+        // or a bound could flip) replay the reference's own expressions.
+        const double rx = qx - fx, ry = qy - fy;
+        const bool near_int = (rx < 1e-9) || (rx > 1. - 1e-9) || (ry < 1e-9) || (ry > 1. - 1e-9);
+        if (__builtin_expect(vote(near_int && live) != 0ull, 0)) {
+            if (near_int) {
+                const bool out = (xr < 0) || (xr >= m.wres) || (yr < 0) || (yr >= m.hres);
+                ci = out ? -1 : min((int)(xr / m.res), m.W - 1);
+                ri = out ? -1 : min((int)(yr / m.res), m.H - 1);
+            }
         }
     }
-    ci = min(max(ci, 0), m.W - 1); // v_med3_i32; also keeps out-of-bounds / idle lanes on valid memory
-    ri = min(max(ri, 0), m.H - 1);
-    const unsigned uri = (unsigned)ri, uci = (unsigned)ci;
-    unsigned tidx = (((uri >> TILE_SHIFT) * (unsigned)m.tiles_per_row + (uci >> TILE_SHIFT)) << (2 * TILE_SHIFT)) |
-                    ((uri & 7u) << TILE_SHIFT) | (uci & 7u);
-    tidx = live ? tidx : 0u; // parked lanes all read cell 0: no extra cache lines
-    const unsigned code = *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(m.cells) + (size_t)(tidx * 2u));
-    const bool use = live & !oob;
-    // common case (d2 < LUT_LDS, i.e. within ~2 m of a wall): one ds_read_b64
-    const unsigned lc = use ? min(code, (unsigned)(LUT_LDS - 1)) : 0u;
+    const unsigned uci = (unsigned)ci, uri = (unsigned)ri;
+    const bool oob = (uci >= (unsigned)m.W) || (uri >= (unsigned)m.H);
+    const bool use = live && !oob;
+    unsigned off = (uci >> 3) * m.strip_bytes + ((uri << 4) | ((uci & 7u) << 1));
+    // buffer load: 32-bit per-lane offset against a scalar descriptor; parked and
+    // out-of-bounds lanes present an out-of-range offset, which the hardware range check
+    // answers with 0 without touching memory (no extra cache lines)
+    off = use ? off : 0xffffffffu;
+    const unsigned code = (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(m.cells_rsrc, (int)off, 0, 0);
+    // common case (d2 < LUT_LDS, i.e. within ~2 m of a wall): one ds_read_b64.  LDS entry
+    // LUT_LDS holds dt[-1,-1] for out-of-bounds reads (:80-81,:103), entry 0 is 0.0 (parked)
+    const unsigned alt = (live && oob) ? (unsigned)LUT_LDS : 0u;
+    const unsigned lc = use ? min(code, (unsigned)(LUT_LDS - 1)) : alt;
     double d = lds_lut[lc];
     // pin the LDS read: otherwise the compiler folds it and the rare global reads below
     // into one flat_load through a selected generic pointer
     asm volatile("" : "+v"(d));
-    const bool far = use & (code >= (unsigned)LUT_LDS);
+    const bool far = code >= (unsigned)LUT_LDS; // only `use` lanes can see a non-zero code
     if (__builtin_expect(vote(far) != 0ull, 0)) {
         if (far) d = (code != (unsigned)CODE_ESC) ? m.lut[code] : m.dt[(size_t)uri * (unsigned)m.W + uci];
     }
-    return (oob & live) ? m.oob : d;
+    return d;
 }
 
 // laser_models.py:167-184: LUT index of beam b.  The reference advances
@@ -135,7 +157,7 @@ struct ScanArgs {
     uint8_t *in_collision;       // [N]
     const uint8_t *pending_reset;// [B]
     int reset_only;              // 1: only envs with pending_reset are processed
-    const uint16_t *beam_order;  // [nb] permutation: k-th beam to be marched (long rays first)
+    const uint16_t *chunk_beam0; // [ceil(nb/64)] first beam of the k-th 64-beam chunk to be marched (long rays first)
     // outputs
     float *out_f32;              // [N,nb] or NULL
     double *out_f64;             // [N,nb] or NULL
@@ -147,14 +169,23 @@ struct ScanArgs {
 // lane (a) finishes its previous beam -- noise, iTTC candidate test, fp32/fp64 store --
 // and (b) takes the next beam of the car.  No LDS staging of the scan: the only LDS
 // use is the 8 KiB distance LUT shared by the workgroup, so occupancy is register-bound.
-template <bool IDENT, bool POW2>
+// STEP: full env step (noise + iTTC + state update); false: ScanSimulator2D.scan(pose, None).
+constexpr int MAX_CHUNKS = 64; // beams are handed out in chunks of 64 (num_beams <= 4096)
+
+template <bool IDENT, bool POW2, bool STEP>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanArgs a)
 {
-    __shared__ double s_lut[LUT_LDS];
-    for (int i = threadIdx.x; i < LUT_LDS; i += SCAN_THREADS) s_lut[i] = a.map.lut[i];
-    __syncthreads();
-
+    __shared__ double s_lut[LUT_LDS + 2];
+    __shared__ int s_chunk0[MAX_CHUNKS];
     const int nb = a.scan.nb;
+    for (int i = threadIdx.x; i < LUT_LDS; i += SCAN_THREADS) s_lut[i] = a.map.lut[i];
+    if (threadIdx.x == 0) s_lut[LUT_LDS] = a.map.oob;
+    for (int i = threadIdx.x; i < ((nb + 63) >> 6); i += SCAN_THREADS) s_chunk0[i] = a.chunk_beam0[i];
+    __syncthreads();
+    MapView mv;
+    mv.cells_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(a.map.cells), 0, (int)a.map.cells_bytes, 0x00020000);
+    mv.init(a.map);
+
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int car = blockIdx.x * SCAN_WAVES + wave; // wave-uniform (scalar)
     if (car >= a.n_cars) return;
@@ -166,27 +197,28 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanArgs a)
     const double eps = a.scan.eps, max_range = a.scan.max_range;
 
     // per-car constants of the finishing stage
-    double *st = a.state ? a.state + (size_t)car * 7 : nullptr;
-    const double vel = st ? st[3] : 0.0;
-    const bool do_ttc = st && vel != 0.0;                 // laser_models.py:206
+    double *st = STEP ? a.state + (size_t)car * 7 : nullptr;
+    const double vel = STEP ? st[3] : 0.0;
+    const bool do_ttc = STEP && vel != 0.0;               // laser_models.py:206
     // iTTC hit needs 0 <= (v - side)/(vel*cos) < thresh, hence |v - side| < thresh*|vel|:
     // only such candidate beams pay the exact fp64 division
     const double cand = a.ttc_thresh * fabs(vel) * 1.000000001;
-    const double *nz = nullptr;
-    if (st && a.noise) nz = a.noise + (size_t)((long long)a.noise_step[car] % a.noise_T) * nb;
+    const double *nz = STEP ? a.noise + (size_t)((long long)a.noise_step[car] % a.noise_T) * nb : nullptr;
+    const double *__restrict__ side = a.side_distances;
     float *o32 = a.out_f32 ? a.out_f32 + (size_t)car * nb : nullptr;
     double *o64 = a.out_f64 ? a.out_f64 + (size_t)car * nb : nullptr;
     bool hit = false;
 
     // finishing stage of one beam: clamp (laser_models.py:143-144), noise (:450-452),
-    // stores, iTTC (:189-217)
-    auto emit = [&](int i, double tot) {
+    // stores, iTTC (:189-217).  nzv / sdv: noise and side distance of the beam, loaded by
+    // the caller ahead of time.
+    auto emit = [&](int i, double tot, double nzv, double sdv) {
         double v = tot > max_range ? max_range : tot;
-        if (nz) v += nz[i];
+        if (STEP) v += nzv;
         if (o32) o32[i] = (float)v;
         if (o64) o64[i] = v;
         if (do_ttc) {
-            const double sd = v - a.side_distances[i];
+            const double sd = v - sdv;
             if (__builtin_expect(fabs(sd) < cand, 0)) {
                 const double proj_vel = vel * a.beam_cosines[i];
                 const double ttc = sd / proj_vel;
@@ -197,17 +229,17 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanArgs a)
 
     // ---- ray march (laser_models.py:107-186) -------------------------------------
     // The first table read of every beam is at the car itself (:129): done once.
-    const double d0 = dist_lookup<IDENT, POW2>(a.map, s_lut, px, py, true);
+    const double d0 = dist_lookup<IDENT, POW2>(mv, s_lut, px, py, true);
     unsigned nlook = (unsigned)nb; // the reference reads the table once per beam before marching
     if (!(d0 > eps && d0 <= max_range)) {
-        for (int i = lane; i < nb; i += WAVE) emit(i, d0);
+        for (int i = lane; i < nb; i += WAVE) emit(i, d0, STEP ? nz[i] : 0.0, STEP ? side[i] : 0.0);
     } else {
         const double td = (double)a.scan.theta_dis;
         double t0w = td * (yaw - a.scan.fov / 2.) / (2. * F110_PI);
         t0w = fmod(t0w, td);
         while (t0w < 0) t0w += td;
 
-        int next = 0;           // wave-uniform: next unassigned slot of beam_order
+        int next = 0;           // wave-uniform: next unassigned slot of the beam order
         bool active = false;
         int beam = -1;          // beam whose result `total` holds (-1: none)
         double x = px, y = py, c = 0, s = 0, total = 0;
@@ -216,16 +248,24 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanArgs a)
             const unsigned long long idle = vote(!active);
             const int nidle = __popcll(idle);
             if (!active) {
-                if (beam >= 0) emit(beam, total);
-                beam = -1;
+                // all independent loads first (one memory round trip): the finished beam's
+                // noise / side distance and the new beam's number
+                const int pb = beam < 0 ? 0 : beam;
+                const double nzv = STEP ? nz[pb] : 0.0;
+                const double sdv = STEP ? side[pb] : 0.0;
                 const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32),
                                     __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
                 const int k = next + rank;
-                if (k < nb) {
-                    const int b = a.beam_order[k];
-                    const int ti = beam_theta_index(t0w, b, a.scan);
-                    s = a.scan.sines[ti];
-                    c = a.scan.cosines[ti];
+                const bool take = k < nb;
+                const int kk = take ? k : 0;
+                const int b = s_chunk0[kk >> 6] + (kk & 63);
+                const int ti = beam_theta_index(t0w, b, a.scan);
+                const double2 cs = a.scan.cs[ti]; // second round trip, overlapped with emit()
+                if (beam >= 0) emit(beam, total, nzv, sdv);
+                beam = -1;
+                if (take) {
+                    c = cs.x;
+                    s = cs.y;
                     x = px + d0 * c;
                     y = py + d0 * s;
                     total = d0;
@@ -241,19 +281,20 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanArgs a)
             const int go = next < nb ? WAVE - REFILL_MIN_IDLE : 0; // keep marching while nact > go
             do {
                 nlook += (unsigned)nact;
-                const double d = dist_lookup<IDENT, POW2>(a.map, s_lut, x, y, active);
+                const double d = dist_lookup<IDENT, POW2>(mv, s_lut, x, y, active);
                 total += d;
                 x += d * c;
                 y += d * s;
-                active = (d > eps) & (total <= max_range);
-                nact = __popcll(vote(active));
+                const bool c1 = d > eps, c2 = total <= max_range;
+                active = c1 && c2;
+                nact = __popcll(vote(c1) & vote(c2)); // two direct compare masks: no bool round trip
             } while (nact > go);
         }
     }
     if (a.lookups && lane == 0) a.lookups[car] += nlook;
 
     // ---- iTTC result (base_classes.py:241-250) ------------------------------------
-    if (st) {
+    if (STEP) {
         const bool any_hit = vote(hit) != 0ull;
         if (lane == 0) {
             if (any_hit) { st[3] = 0.; st[4] = 0.; st[5] = 0.; st[6] = 0.; }
