@@ -10,6 +10,15 @@
 
 namespace f110 {
 
+// clamp x to [lo, hi] in one instruction (the compiler only forms v_med3_i32 when it can
+// prove lo <= hi, which it cannot for a runtime map size)
+__device__ inline int med3_i32(int x, int lo, int hi)
+{
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(lo), "s"(hi));
+    return r;
+}
+
 // wave-wide vote straight on the condition mask (HIP's __ballot round-trips through a VGPR)
 __device__ inline unsigned long long vote(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
@@ -22,24 +31,32 @@ constexpr int WAVE = 64;
 #endif
 constexpr int SCAN_WAVES = F110_SCAN_WAVES;   // cars per workgroup (one wavefront each)
 constexpr int SCAN_THREADS = SCAN_WAVES * WAVE;
-constexpr int LUT_LDS = 1024;                 // distance LUT entries staged in LDS (d2 < 1024), 8 KiB
-constexpr int CODE_ESC = 65535;               // cell code: read the fp64 table instead
 constexpr int REFILL_MIN_IDLE = F110_REFILL_MIN_IDLE; // refill the wave's beam slots once this many lanes idle
 
-// The u16 cell table is stored in 8-column strips: cell (r, c) lives at
-// [c >> 3][r][c & 7], so one 128-B cache line holds an 8x8-cell block (rows 8k..8k+7 of
-// a strip).  The 64 rays of a wave sample neighbouring points, so a gather touches a
-// few lines instead of one line per lane (row-major measured ~40 distinct lines per
-// 64-lane gather and made the kernel L1-tag-rate bound), and the offset is one
-// multiply-add: (c >> 3) * strip_bytes + r * 16 + (c & 7) * 2.
+// Cell table.  Each map cell stores a 16-bit code of its exact squared distance d2 (in
+// cells) to the nearest obstacle: code = d2 for d2 < 1023, d2 + 1 for 1023 <= d2 <= 65533,
+// CODE_ESC otherwise (also for cells of a user table that are not resolution*sqrt(int));
+// the distance itself comes from a fp64 LUT (first 1023 entries in LDS).  The table has a
+// one-cell BORDER on every side holding CODE_BORDER, whose LDS slot holds dt[-1,-1]: the
+// reference's out-of-bounds read (laser_models.py:80-81,:103) becomes an ordinary lookup
+// of a clamped index -- no bounds compare, no select in the march loop.
+// Layout: 8-column strips, cell (r, c) of the padded table at [c >> 3][r][c & 7], so one
+// 128-B cache line holds an 8x8-cell block.  The 64 rays of a wave sample neighbouring
+// points, so a gather touches a few lines instead of one line per lane (row-major
+// measured ~40 distinct lines per 64-lane gather and made the kernel L1-tag-rate bound),
+// and the byte offset is one multiply-add: (c >> 3) * strip_bytes + r * 16 + (c & 7) * 2.
+constexpr int LUT_LDS = 1024;                 // LDS LUT slots: d2 < 1023 plus the border slot
+constexpr unsigned CODE_BORDER = LUT_LDS - 1; // 1023
+constexpr unsigned CODE_ESC = 65535;          // read the fp64 table instead
+
 struct MapDev {
-    const uint16_t *cells;  // strips [ceil(W/8)][Hp][8] of min(d2, 65535); 65535 = escape to dt
+    const uint16_t *cells;  // padded strips [ceil((W+2)/8)][Hp][8]
     unsigned cells_bytes;
-    unsigned strip_bytes;   // Hp * 16, Hp = H rounded up to a multiple of 8
-    const double *lut;      // [65535] resolution*sqrt(d2)
+    unsigned strip_bytes;   // Hp * 16, Hp = H + 2 rounded up to a multiple of 8
+    const double *lut;      // [65534] resolution*sqrt(d2), indexed by d2
     const double *dt;       // [H*W] exact fp64 distance table (escape path, rarely touched)
     int H, W;
-    double res, rinv, ox, oy, oc, os, wres, hres, oob; // oob = dt[H-1][W-1] (laser_models.py:80-81,103)
+    double res, rinv, ox, oy, oc, os, wres, hres, oob; // oob = dt[H-1][W-1]
 };
 
 // device-side view of MapDev with the cell table behind a buffer resource descriptor
@@ -66,9 +83,8 @@ struct ScanDev {
 // laser_models.py:56-104: (x, y) -> distance-table value, branch-free.  IDENT: origin
 // yaw == 0 (c=1, s=0: the rotation is the identity in exact arithmetic).  POW2:
 // resolution is a power of two, so q = x_rot * (1/res) IS the reference's quotient and
-// "x_rot < 0 or x_rot >= width*res" (:79) is exactly "floor(q) outside [0, W)".
-// Lanes with `live == false` execute too (no exec-mask juggling in the march loop) but
-// read cell 0 / LUT entry 0 and return 0.0, which parks their ray.
+// "x_rot < 0 or x_rot >= width*res" (:79) is exactly "floor(q) outside [0, W)", which the
+// clamp to [-1, W] maps onto the table's border.
 template <bool IDENT, bool POW2>
 __device__ inline double dist_lookup(const MapView &m, const double *lds_lut, double x, double y, bool live)
 {
@@ -78,14 +94,14 @@ __device__ inline double dist_lookup(const MapView &m, const double *lds_lut, do
     else { xr = xt * m.oc + yt * m.os; yr = -xt * m.os + yt * m.oc; }
     const double qx = xr * m.rinv, qy = yr * m.rinv;
     const double fx = floor(qx), fy = floor(qy);
-    int ci = (int)fx, ri = (int)fy; // saturating; negative / huge values fail the range test below
+    int ci = (int)fx, ri = (int)fy; // saturating conversion; the clamp below finishes the job
     if (!POW2) {
         // int(x_rot/resolution) and the bounds test need the IEEE quotient: x_rot*(1/res) is
         // within ~2e-12 of it, so only quotients within 1e-9 of an integer (where truncation
         // or a bound could flip) replay the reference's own expressions.
         const double rx = qx - fx, ry = qy - fy;
         const bool near_int = (rx < 1e-9) || (rx > 1. - 1e-9) || (ry < 1e-9) || (ry > 1. - 1e-9);
-        if (__builtin_expect(vote(near_int && live) != 0ull, 0)) {
+        if (__builtin_expect(vote(near_int) != 0ull, 0)) {
             if (near_int) {
                 const bool out = (xr < 0) || (xr >= m.wres) || (yr < 0) || (yr >= m.hres);
                 ci = out ? -1 : min((int)(xr / m.res), m.W - 1);
@@ -93,26 +109,24 @@ __device__ inline double dist_lookup(const MapView &m, const double *lds_lut, do
             }
         }
     }
-    const unsigned uci = (unsigned)ci, uri = (unsigned)ri;
-    const bool oob = (uci >= (unsigned)m.W) || (uri >= (unsigned)m.H);
-    const bool use = live && !oob;
-    unsigned off = (uci >> 3) * m.strip_bytes + ((uri << 4) | ((uci & 7u) << 1));
-    // buffer load: 32-bit per-lane offset against a scalar descriptor; parked and
-    // out-of-bounds lanes present an out-of-range offset, which the hardware range check
-    // answers with 0 without touching memory (no extra cache lines)
-    off = use ? off : 0xffffffffu;
+    const int cc = med3_i32(ci, -1, m.W) + 1;  // padded column 0..W+1
+    const int rr = med3_i32(ri, -1, m.H);      // padded row - 1 (the +1 is the +16 below)
+    unsigned off = __umul24((unsigned)cc >> 3, m.strip_bytes) + (((unsigned)rr << 4) + 16u) + (((unsigned)cc & 7u) << 1);
+#ifndef F110_PARKED_LOAD
+    // a finished ray presents an out-of-range offset: the hardware range check answers 0
+    // (= d2 0 = distance 0.0, which parks the ray) without occupying the L1 tag pipeline
+    off = live ? off : 0xffffffffu;
+#endif
+    // buffer load: 32-bit per-lane offset against a scalar descriptor
     const unsigned code = (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(m.cells_rsrc, (int)off, 0, 0);
-    // common case (d2 < LUT_LDS, i.e. within ~2 m of a wall): one ds_read_b64.  LDS entry
-    // LUT_LDS holds dt[-1,-1] for out-of-bounds reads (:80-81,:103), entry 0 is 0.0 (parked)
-    const unsigned alt = (live && oob) ? (unsigned)LUT_LDS : 0u;
-    const unsigned lc = use ? min(code, (unsigned)(LUT_LDS - 1)) : alt;
-    double d = lds_lut[lc];
+    // common case: one ds_read_b64 (d2 < 1023: within ~2 m of a wall; or the border slot)
+    double d = lds_lut[min(code, CODE_BORDER)];
     // pin the LDS read: otherwise the compiler folds it and the rare global reads below
     // into one flat_load through a selected generic pointer
     asm volatile("" : "+v"(d));
-    const bool far = code >= (unsigned)LUT_LDS; // only `use` lanes can see a non-zero code
+    const bool far = code > CODE_BORDER;
     if (__builtin_expect(vote(far) != 0ull, 0)) {
-        if (far) d = (code != (unsigned)CODE_ESC) ? m.lut[code] : m.dt[(size_t)uri * (unsigned)m.W + uci];
+        if (far) d = (code != CODE_ESC) ? m.lut[code - 1u] : m.dt[(size_t)(unsigned)rr * (unsigned)m.W + (unsigned)(cc - 1)];
     }
     return d;
 }
@@ -164,22 +178,23 @@ struct ScanArgs {
     uint32_t *lookups;           // [N] or NULL (accumulated)
 };
 
-// One wavefront per car.  Lanes own rays; a finished ray parks its lane (the lookup
-// returns 0.0 for it) until at least REFILL_MIN_IDLE lanes are idle, then every idle
+// One wavefront per car.  Lanes own rays; a finished ray idles (see FREEZE) until at least REFILL_MIN_IDLE lanes are idle, then every idle
 // lane (a) finishes its previous beam -- noise, iTTC candidate test, fp32/fp64 store --
 // and (b) takes the next beam of the car.  No LDS staging of the scan: the only LDS
 // use is the 8 KiB distance LUT shared by the workgroup, so occupancy is register-bound.
 // STEP: full env step (noise + iTTC + state update); false: ScanSimulator2D.scan(pose, None).
 constexpr int MAX_CHUNKS = 64; // beams are handed out in chunks of 64 (num_beams <= 4096)
 
-template <bool IDENT, bool POW2, bool STEP>
+// FREEZE: the table holds values in (0, eps] (or none equal to 0), so a finished ray
+// cannot be left to its own devices; otherwise a ray that stopped on d == 0 stays put by
+// itself and one that ran past max_range keeps growing and is clamped when it is emitted.
+template <bool IDENT, bool POW2, bool STEP, bool FREEZE>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanArgs a)
 {
-    __shared__ double s_lut[LUT_LDS + 2];
+    __shared__ double s_lut[LUT_LDS];
     __shared__ int s_chunk0[MAX_CHUNKS];
     const int nb = a.scan.nb;
-    for (int i = threadIdx.x; i < LUT_LDS; i += SCAN_THREADS) s_lut[i] = a.map.lut[i];
-    if (threadIdx.x == 0) s_lut[LUT_LDS] = a.map.oob;
+    for (int i = threadIdx.x; i < LUT_LDS; i += SCAN_THREADS) s_lut[i] = i < (int)CODE_BORDER ? a.map.lut[i] : a.map.oob;
     for (int i = threadIdx.x; i < ((nb + 63) >> 6); i += SCAN_THREADS) s_chunk0[i] = a.chunk_beam0[i];
     __syncthreads();
     MapView mv;
@@ -274,14 +289,28 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanArgs a)
                 }
             }
             next += nidle;
+#if defined(F110_COUNT_MODE) && F110_COUNT_MODE == 2 // diagnostics: refills
+            nlook += 1;
+#endif
             int nact = __popcll(vote(active));
             if (nact == 0) break;
             // ---- march phase: every lane steps (idle lanes are parked by d = 0) until
             // enough lanes are idle again or, once no beams are left, the wave has drained ----
             const int go = next < nb ? WAVE - REFILL_MIN_IDLE : 0; // keep marching while nact > go
             do {
+#if !defined(F110_COUNT_MODE)
                 nlook += (unsigned)nact;
+#elif F110_COUNT_MODE == 1   // diagnostics: wave iterations
+                nlook += 1;
+#elif F110_COUNT_MODE == 3   // diagnostics: wave iterations of the drain phase
+                nlook += go == 0 ? 1 : 0;
+#endif
+#ifndef F110_PARKED_LOAD
                 const double d = dist_lookup<IDENT, POW2>(mv, s_lut, x, y, active);
+#else
+                double d = dist_lookup<IDENT, POW2>(mv, s_lut, x, y, active);
+                if (FREEZE) d = active ? d : 0.0; // park finished rays explicitly
+#endif
                 total += d;
                 x += d * c;
                 y += d * s;

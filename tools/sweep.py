@@ -16,13 +16,14 @@ ap.add_argument('--agents', type=int, default=1)
 ap.add_argument('--steps', type=int, default=60)
 ap.add_argument('--warmup', type=int, default=40)
 a = ap.parse_args()
-env = F110VecEnv(a.envs, map=workload.EXAMPLE_MAP, num_agents=a.agents, autoreset=True)
+env = F110VecEnv(a.envs, map=workload.EXAMPLE_MAP, num_agents=a.agents, autoreset=True, count_lookups=True)
 dev = env.device
 poses = torch.as_tensor(workload.spawn_poses(a.envs, a.agents), device=dev)
 acts = torch.as_tensor(workload.action_pool(8, a.envs, a.agents), device=dev)
 env.reset(poses)
 for k in range(a.warmup):
     env.step(acts[k % 8])
+env.eng.t['lookups'].zero_()
 env.eng.profile_begin(a.steps)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
@@ -31,6 +32,7 @@ for k in range(a.steps):
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 ms, n = env.eng.profile_end()
-print('%-40s ms/step %.3f  scan_ms %.3f  Msteps/s %.2f' % (os.path.basename(os.environ.get('F110_LIB', 'default')),
-      dt / a.steps * 1e3, ms / n, a.envs * a.steps / dt / 1e6), flush=True)
+cnt = env.eng.t['lookups'].to(torch.int64).sum().item() / (a.steps * a.envs * a.agents)
+print('%-40s ms/step %.3f  scan_ms %.3f  Msteps/s %.2f  count/car-step %.1f' % (os.path.basename(os.environ.get('F110_LIB', 'default')),
+      dt / a.steps * 1e3, ms / n, a.envs * a.steps / dt / 1e6, cnt), flush=True)
 env.close()
