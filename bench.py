@@ -24,13 +24,32 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
+def usable_cores():
+    """CPU threads this process may really use: the affinity mask capped by the cgroup
+    CPU quota (a GPU box hands a 1-GPU job a slice of a many-core host)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        try:
+            q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            p = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except Exception:
+            pass
+    return min(n, 64)
+
+
 def cpu_baseline(num_agents, budget_s=12.0):
     """The CPU oracle (oracle/f110_oracle.c, a scalar fp64 port of the reference's
     Numba path) timed on this box's host cores on a bounded sample of the same
     workload: same map, spawn distribution, action distribution, noise, autoreset."""
     import oracle
     from red_gym_amd import workload
-    cores = len(os.sched_getaffinity(0))
+    cores = usable_cores()
     sc = oracle.Scanner(1080, 2 * np.pi)
     sc.set_map(workload.EXAMPLE_MAP + '.yaml', '.png')
     B = 64 * cores
@@ -136,6 +155,8 @@ def main():
             bytes_per_launch = (tot_lookups / max(n_launch, 1)) * 4.0 + cars * (1080 * 4 + 72)
             avg_s = scan_ms * 1e-3 / max(n_launch, 1)
             achieved = bytes_per_launch / avg_s / 1e9
+            # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE in separate
+            # runs of this same workload; tools/profile.sh writes profiles/traffic.json)
             traffic = None
             tp = os.path.join(ROOT, 'profiles', 'traffic.json')
             if os.path.exists(tp):

@@ -27,7 +27,7 @@ constexpr int WAVE = 64;
 #define F110_SCAN_WAVES 2
 #endif
 #ifndef F110_REFILL_MIN_IDLE
-#define F110_REFILL_MIN_IDLE 32
+#define F110_REFILL_MIN_IDLE 40
 #endif
 constexpr int SCAN_WAVES = F110_SCAN_WAVES;   // cars per workgroup (one wavefront each)
 constexpr int SCAN_THREADS = SCAN_WAVES * WAVE;
