@@ -79,6 +79,71 @@ def cpu_baseline(num_agents, budget_s=12.0):
             'single_thread_value': 64 * 6 / dt1}
 
 
+class Ranks(object):
+    """One process per GPU (RANK / LOCAL_RANK / WORLD_SIZE from torch.distributed.run).
+    The step path has no collective: ranks only meet at the barriers around the timed
+    region and to take the MAX of the elapsed time.  backend 'nccl' (= RCCL) on GPUs,
+    'gloo' in the CPU tests."""
+
+    def __init__(self, backend='nccl', device=None):
+        import torch.distributed as dist
+        self.rank = int(os.environ.get('RANK', '0'))
+        self.local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+        self.world = int(os.environ.get('WORLD_SIZE', '1'))
+        self.backend, self.device, self.dist = backend, device, dist
+        if self.world > 1:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            if backend == 'nccl':
+                dist.init_process_group('nccl', device_id=device)
+            else:
+                dist.init_process_group(backend)
+
+    def sync_device(self):
+        if self.device is not None:
+            import torch
+            torch.cuda.synchronize(self.device)
+
+    def barrier(self):
+        self.sync_device()
+        if self.world > 1:
+            if self.backend == 'nccl':
+                self.dist.barrier(device_ids=[self.local_rank])
+            else:
+                self.dist.barrier()
+        self.sync_device()
+
+    def max_over_ranks(self, seconds):
+        if self.world == 1:
+            return seconds
+        import torch
+        t = torch.tensor([seconds], dtype=torch.float64, device=self.device if self.backend == 'nccl' else 'cpu')
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        if self.world > 1:
+            self.barrier()
+            self.dist.destroy_process_group()
+
+
+def timed_steps(ranks, step_fn, K):
+    """EXACTLY K steps bracketed by barrier + device sync on both sides; returns the MAX
+    over ranks of the elapsed seconds."""
+    ranks.barrier()
+    t0 = time.perf_counter()
+    for k in range(K):
+        step_fn(k)
+    ranks.barrier()
+    return ranks.max_over_ranks(time.perf_counter() - t0)
+
+
+def rank_workload(rank, B, A, pool=16):
+    """Each rank owns an independent shard of envs: its own spawn jitter (seed 2025+rank)
+    and action stream (seed 777+rank); SURVEY 8(d)."""
+    from red_gym_amd import workload
+    return workload.spawn_poses(B, A, rank), workload.action_pool(pool, B, A, rank)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -91,57 +156,34 @@ def main():
                     help='do not bracket the scan kernel with hipEvents (roofline becomes null)')
     args = ap.parse_args()
 
-    rank = int(os.environ.get('RANK', '0'))
+    import torch
+    from red_gym_amd import F110VecEnv, workload
+
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    ranks = Ranks('nccl', dev)
+    rank, world = ranks.rank, ranks.world
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit('bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)' % args.gpus)
         args.gpus = world
 
-    import torch
-    import torch.distributed as dist
-    from red_gym_amd import F110VecEnv, workload
-
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
-
     B, A, K, W = args.envs, args.agents, args.steps, args.warmup
     env = F110VecEnv(B, map=workload.EXAMPLE_MAP, map_ext='.png', num_agents=A, timestep=0.01, seed=12345,
                      device=local_rank, autoreset=True, count_lookups=True)
-    poses = torch.as_tensor(workload.spawn_poses(B, A, rank), device=dev)
     POOL = 16
-    acts = torch.as_tensor(workload.action_pool(POOL, B, A, rank), device=dev)  # resident in HBM
+    poses_np, acts_np = rank_workload(rank, B, A, POOL)
+    poses = torch.as_tensor(poses_np, device=dev)
+    acts = torch.as_tensor(acts_np, device=dev)  # resident in HBM before the timed region
     env.reset(poses)
     for k in range(W):
         env.step(acts[k % POOL])
     lookups = env.eng.t['lookups']
     lookups.zero_()
-
-    def barrier():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier(device_ids=[local_rank])
-        torch.cuda.synchronize(dev)
-
     if not args.no_scan_events:
         env.eng.profile_begin(K)
-    barrier()
-    t0 = time.perf_counter()
-    for k in range(K):
-        env.step(acts[(W + k) % POOL])
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier(device_ids=[local_rank])
-        torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = timed_steps(ranks, lambda k: env.step(acts[(W + k) % POOL]), K)
 
     out = None
     if rank == 0:
@@ -182,9 +224,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(A)
     env.close()
-    if world > 1:
-        dist.barrier(device_ids=[local_rank])
-        dist.destroy_process_group()
+    ranks.close()
     if rank == 0:
         print(json.dumps(out), flush=True)
 

@@ -1,0 +1,81 @@
+"""The reference's Python surface on top of the HIP path: gym.make('f110_gym:f110-v0'),
+the waypoint-follow caller (config 1), ScanSimulator2D and Simulator mirrors."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import oracle  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_waypoint_follow_example_config1():
+    """examples/waypoint_follow.py: gym.make -> reset -> plan/step loop until done.
+    Reference result: 3329 steps, 33.29 s sim time, 2 laps, no collision."""
+    sys.path.insert(0, os.path.join(ROOT, 'examples'))
+    import waypoint_follow
+    steps, laptime, obs = waypoint_follow.main()
+    assert steps == 3329 and abs(laptime - 33.29) < 1e-9
+    assert obs['lap_counts'][0] == 2 and obs['collisions'][0] == 0
+
+
+def test_scan_simulator_mirror(assets, golden):
+    from f110_gym.envs.laser_models import ScanSimulator2D
+    g = golden('g1_scan.npz')
+    sim = ScanSimulator2D(1080, 2 * np.pi)
+    with pytest.raises(ValueError, match='Map is not set'):
+        sim.scan(np.zeros(3), None)
+    assert sim.set_map(os.path.join(assets, 'example_map.yaml'), '.png') is True
+    assert sim.get_increment() == 2 * np.pi / 1079
+    for k in (0, 9, 41):
+        assert np.array_equal(sim.scan(g['ex_poses'][k], None), g['ex_scans'][k])
+    # laser_models.py:554-580 test_rng: same seed -> same noisy scan; consecutive scans differ
+    rng1, rng2 = np.random.default_rng(seed=12345), np.random.default_rng(seed=12345)
+    s1, s2 = sim.scan(g['ex_poses'][0], rng1), sim.scan(g['ex_poses'][0], rng2)
+    assert np.array_equal(s1, s2) and not np.array_equal(s1, sim.scan(g['ex_poses'][0], rng1))
+    gn = golden('g2_noise.npz')['seed12345'][0]
+    assert np.array_equal(s1, g['ex_scans'][0] + gn)
+
+
+def test_simulator_mirror_matches_golden(assets, golden):
+    from f110_gym.envs.base_classes import Integrator, Simulator
+    g = golden('g7_sim.npz')
+    sim = Simulator(oracle.DEFAULT_PARAMS, 2, 12345, 2 * np.pi, time_step=0.01, integrator=Integrator.RK4)
+    with pytest.raises(ValueError):
+        sim.reset(g['a2_start'])
+    sim.set_map(os.path.join(assets, 'example_map.yaml'), '.png')
+    with pytest.raises(ValueError, match='Number of poses'):
+        sim.reset(np.zeros((3, 3)))
+    with pytest.raises(IndexError):
+        sim.update_params(oracle.DEFAULT_PARAMS, agent_idx=2)
+    sim.reset(g['a2_start'])
+    obs = sim.step(np.zeros((2, 2)))
+    assert set(obs) == {'ego_idx', 'scans', 'poses_x', 'poses_y', 'poses_theta', 'linear_vels_x', 'linear_vels_y',
+                        'ang_vels_z', 'collisions'}
+    for k in range(120):
+        obs = sim.step(g['a2_actions'][k])
+        assert np.allclose(sim.agents[0].state, g['a2_states'][k, 0], rtol=0, atol=1e-9)
+        assert np.allclose(sim.agents[1].state, g['a2_states'][k, 1], rtol=0, atol=1e-9)
+        assert np.array_equal(obs['collisions'], g['a2_collisions'][k])
+        assert np.array_equal(sim.collision_idx, g['a2_collision_idx'][k])
+    assert g['a2_collisions'][:120].any()
+
+
+def test_f110env_kwargs_and_errors(assets):
+    from red_gym_amd import compat
+    compat.install_missing()
+    import gym
+    env = gym.make('f110_gym:f110-v0', map=os.path.join(assets, 'example_map'), map_ext='.png', num_agents=2,
+                   render_options={'ignored': True})
+    assert env.num_agents == 2 and env.timestep == 0.01 and env.ego_idx == 0 and env.seed == 12345
+    with pytest.raises(ValueError, match='Number of poses'):
+        env.reset(np.zeros((1, 3)))
+    obs, r, done, info = env.reset(np.array([[0.7, 0.0, 1.37], [0.7, -1.5, 1.37]]))
+    assert len(obs['scans']) == 2 and obs['collisions'].shape == (2,) and info['checkpoint_done'].shape == (2,)
+    assert obs['linear_vels_y'] == [0., 0.] and r == 0.01
+    env.render()  # accepted, no-op
+    env.close()
