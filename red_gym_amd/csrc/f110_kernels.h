@@ -45,7 +45,10 @@ constexpr int REFILL_MIN_IDLE = F110_REFILL_MIN_IDLE; // refill the wave's beam 
 // points, so a gather touches a few lines instead of one line per lane (row-major
 // measured ~40 distinct lines per 64-lane gather and made the kernel L1-tag-rate bound),
 // and the byte offset is one multiply-add: (c >> 3) * strip_bytes + r * 16 + (c & 7) * 2.
-constexpr int LUT_LDS = 1024;                 // LDS LUT slots: d2 < 1023 plus the border slot
+#ifndef F110_LUT_LDS
+#define F110_LUT_LDS 1024
+#endif
+constexpr int LUT_LDS = F110_LUT_LDS;          // LDS LUT slots: d2 < LUT_LDS-1 plus the border slot
 constexpr unsigned CODE_BORDER = LUT_LDS - 1; // 1023
 constexpr unsigned CODE_ESC = 65535;          // read the fp64 table instead
 
@@ -189,7 +192,10 @@ constexpr int MAX_CHUNKS = 64; // beams are handed out in chunks of 64 (num_beam
 // cannot be left to its own devices; otherwise a ray that stopped on d == 0 stays put by
 // itself and one that ran past max_range keeps growing and is clamped when it is emitted.
 template <bool IDENT, bool POW2, bool STEP, bool FREEZE>
-__global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanArgs a)
+#ifndef F110_SCAN_MIN_WAVES
+#define F110_SCAN_MIN_WAVES 8
+#endif
+__global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel(ScanArgs a)
 {
     __shared__ double s_lut[LUT_LDS];
     __shared__ int s_chunk0[MAX_CHUNKS];
