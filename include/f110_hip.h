@@ -87,7 +87,8 @@ typedef struct {
     uint8_t *in_collision;  /* [N]    RaceCar.in_collision (iTTC only) */
     int32_t *lap_counts;    /* [N]    f110_env.py:238 */
     double *lap_times;      /* [N]    f110_env.py:240 */
-    uint8_t *done;          /* [B]    f110_env.py:242 */
+    uint8_t *done;          /* [B]    f110_env.py:242 (0/1, so the buffer may be a bool tensor) */
+    uint8_t *checkpoint_done; /* [N]  info['checkpoint_done'] = toggles >= 4 (f110_env.py:244), or NULL */
     uint32_t *lookups;      /* [N]    distance-table reads per car, ACCUMULATED over steps until the caller
                                       zeroes it (instrumentation for the byte model), or NULL */
 } f110_buffers;

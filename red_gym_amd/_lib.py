@@ -28,7 +28,7 @@ class Config(C.Structure):
 
 BUFFER_FIELDS = ['state', 'steer_buf', 'steer_cnt', 'noise_step', 'spawn', 'start_rot', 'near_start',
                  'toggles', 'current_time', 'pending_reset', 'scans', 'scans_f64', 'pose_snap',
-                 'collisions', 'collision_idx', 'in_collision', 'lap_counts', 'lap_times', 'done', 'lookups']
+                 'collisions', 'collision_idx', 'in_collision', 'lap_counts', 'lap_times', 'done', 'checkpoint_done', 'lookups']
 
 
 class Buffers(C.Structure):

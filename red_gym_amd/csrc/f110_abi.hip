@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <utility>
@@ -399,7 +400,7 @@ extern "C" int f110_bind(f110_handle *h, const f110_buffers *b)
                          b->pose_snap, b->collisions, b->collision_idx, b->in_collision, b->lap_counts,
                          b->lap_times, b->done};
     for (const void *p : req)
-        if (!p) return fail(F110_E_INVALID, "f110_bind: a required buffer is NULL (only scans_f64 and lookups are optional)");
+        if (!p) return fail(F110_E_INVALID, "f110_bind: a required buffer is NULL (only scans_f64, checkpoint_done and lookups are optional)");
     h->bufs = *b;
     h->bound = true;
     return F110_OK;
@@ -417,7 +418,7 @@ static ScanDev scan_dev(const f110_handle *h)
 template <bool STEP, bool FREEZE>
 static int launch_scan_t(f110_handle *h, const ScanArgs &a, hipStream_t st)
 {
-    const dim3 grid((a.n_cars + SCAN_WAVES - 1) / SCAN_WAVES), block(SCAN_THREADS);
+    const dim3 grid((a.n_cars * a.wpc + SCAN_WAVES - 1) / SCAN_WAVES), block(SCAN_THREADS);
     if (h->ident && h->pow2) hipLaunchKernelGGL((scan_kernel<true, true, STEP, FREEZE>), grid, block, 0, st, a);
     else if (h->ident) hipLaunchKernelGGL((scan_kernel<true, false, STEP, FREEZE>), grid, block, 0, st, a);
     else if (h->pow2) hipLaunchKernelGGL((scan_kernel<false, true, STEP, FREEZE>), grid, block, 0, st, a);
@@ -426,8 +427,25 @@ static int launch_scan_t(f110_handle *h, const ScanArgs &a, hipStream_t st)
     return F110_OK;
 }
 
-static int launch_scan(f110_handle *h, const ScanArgs &a, hipStream_t st)
+// Waves per car.  Measured on MI355X (profiles/r01g): splitting a car's beams over 2/4/8
+// waves does not pay even at 4 096 cars (0.119 / 0.113 / 0.122 / 0.149 ms) -- per-wave
+// prologue and the shorter queues' tails eat the extra parallelism -- so one wave per car
+// is the default; F110_WPC overrides it for experiments.
+static int waves_per_car(int n_cars, int num_beams)
 {
+    static const char *env = getenv("F110_WPC");
+    int wpc = env ? atoi(env) : 1;
+    if (wpc != 2 && wpc != 4 && wpc != 8) wpc = 1;
+    const int nch = (num_beams + 63) / 64;
+    while (wpc > 1 && wpc > nch) wpc /= 2;
+    (void)n_cars;
+    return wpc;
+}
+
+static int launch_scan(f110_handle *h, const ScanArgs &a_in, hipStream_t st)
+{
+    ScanArgs a = a_in;
+    a.wpc = waves_per_car(a.n_cars, a.scan.nb);
     if (h->freeze) return a.state ? launch_scan_t<true, true>(h, a, st) : launch_scan_t<false, true>(h, a, st);
     return a.state ? launch_scan_t<true, false>(h, a, st) : launch_scan_t<false, false>(h, a, st);
 }
@@ -440,7 +458,7 @@ static int run_step(f110_handle *h, const double *actions, int reset_only, hipSt
     DynArgs d;
     d.n_cars = N; d.agents = c.num_agents; d.state = b.state; d.steer_buf = b.steer_buf; d.steer_cnt = b.steer_cnt;
     d.noise_step = b.noise_step; d.actions = actions; d.spawn = b.spawn; d.pending_reset = b.pending_reset;
-    d.reset_only = reset_only; d.pose_snap = b.pose_snap; d.params = h->params; d.time_step = c.timestep;
+    d.reset_only = reset_only; d.pose_snap = b.pose_snap; d.in_collision = b.in_collision; d.params = h->params; d.time_step = c.timestep;
     d.integrator = c.integrator;
     hipLaunchKernelGGL(dynamics_kernel, dim3((N + 255) / 256), dim3(256), 0, st, d);
     HIP_TRY(hipGetLastError());
@@ -463,7 +481,7 @@ static int run_step(f110_handle *h, const double *actions, int reset_only, hipSt
     if (c.num_agents > 1) {
         OppArgs o;
         o.n_cars = N; o.agents = c.num_agents; o.nb = c.num_beams; o.state = b.state; o.pose_snap = b.pose_snap;
-        o.scan_angles = h->d_scan_angles; o.car_length = h->params.v[P_LENGTH]; o.car_width = h->params.v[P_WIDTH];
+        o.in_collision = b.in_collision; o.scan_angles = h->d_scan_angles; o.car_length = h->params.v[P_LENGTH]; o.car_width = h->params.v[P_WIDTH];
         o.pending_reset = b.pending_reset; o.reset_only = reset_only; o.scans32 = b.scans; o.scans64 = b.scans_f64;
         hipLaunchKernelGGL(opponents_kernel, dim3((N + 3) / 4), dim3(256), 0, st, o);
         HIP_TRY(hipGetLastError());
@@ -471,10 +489,10 @@ static int run_step(f110_handle *h, const double *actions, int reset_only, hipSt
 
     EnvArgs e;
     e.n_envs = c.num_envs; e.agents = c.num_agents; e.ego_idx = c.ego_idx; e.autoreset = c.autoreset;
-    e.reset_only = reset_only; e.state = b.state; e.pose_snap = b.pose_snap; e.spawn = b.spawn;
+    e.reset_only = reset_only; e.state = b.state; e.noise_step = b.noise_step; e.pose_snap = b.pose_snap; e.spawn = b.spawn;
     e.in_collision = b.in_collision; e.collisions = b.collisions; e.collision_idx = b.collision_idx;
     e.start_rot = b.start_rot; e.near_start = b.near_start; e.toggles = b.toggles; e.lap_counts = b.lap_counts;
-    e.lap_times = b.lap_times; e.current_time = b.current_time; e.pending_reset = b.pending_reset; e.done = b.done;
+    e.lap_times = b.lap_times; e.current_time = b.current_time; e.pending_reset = b.pending_reset; e.done = b.done; e.checkpoint_done = b.checkpoint_done;
     e.time_step = c.timestep; e.car_length = h->params.v[P_LENGTH]; e.car_width = h->params.v[P_WIDTH];
     hipLaunchKernelGGL(env_kernel, dim3((c.num_envs + 127) / 128), dim3(128), 0, st, e);
     HIP_TRY(hipGetLastError());

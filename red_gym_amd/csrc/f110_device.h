@@ -289,43 +289,51 @@ __device__ inline double get_range(double ox, double oy, double v3x, double v3y,
     return distance;
 }
 
-// wave-wide first-index arg-min of |scan_angles[i] - a| (np.argmin semantics)
-__device__ inline int wave_argmin_abs_diff(const double *__restrict__ scan_angles, int nb, double a, int lane)
+// First-index arg-min of |scan_angles[i] - a| (np.argmin semantics) for the strictly
+// increasing beam-angle table (base_classes.py:131-132): fl(scan_angles[i] - a) is monotone
+// in i, so |.| falls while negative and rises once positive -- the minimum sits at the last
+// entry <= a or its successor.  A linear estimate lands within a step or two of it; the two
+// loops make the result independent of the estimate.  NaN -> nb (caller bails out).
+__device__ inline int argmin_abs_diff_sorted(const double *__restrict__ scan_angles, int nb, double a)
 {
-    double bv = __builtin_inf();
-    int bi = 0x7fffffff;
-    for (int i = lane; i < nb; i += 64) {
-        double v = fabs(scan_angles[i] - a);
-        if (v < bv) { bv = v; bi = i; }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        double ov = __shfl_xor(bv, off);
-        int oi = __shfl_xor(bi, off);
-        if (ov < bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-    }
-    return bi;
+    if (!(a == a)) return nb;
+    const double sa0 = scan_angles[0];
+    const double inv_incr = (double)(nb - 1) / (scan_angles[nb - 1] - sa0);
+    double est = (a - sa0) * inv_incr;
+    est = est < 0. ? 0. : (est > (double)(nb - 1) ? (double)(nb - 1) : est);
+    int k = (int)est;
+    while (k + 1 < nb && scan_angles[k + 1] <= a) k++;
+    while (k > 0 && scan_angles[k] > a) k--;
+    // candidates k and k+1 (first minimum wins)
+    const double vk = fabs(scan_angles[k] - a);
+    if (k + 1 < nb && fabs(scan_angles[k + 1] - a) < vk) return k + 1;
+    return k;
 }
 
-// laser_models.py:283-315 (wave-cooperative)
+// laser_models.py:283-315: lane v (mod 4) handles corner v, the span is the min/max of
+// the four indices.
 __device__ inline void blocked_view_indices(double px, double py, double pyaw, const double verts[4][2],
                                             const double *__restrict__ scan_angles, int nb, int lane,
                                             int &min_ind, int &max_ind)
 {
-    double ex = cos(pyaw), ey = sin(pyaw);
-    double ego_ang = atan2(ey, ex);
-    int lo = 0, hi = 0;
+    const double ex = cos(pyaw), ey = sin(pyaw);
+    const double ego_ang = atan2(ey, ex);
+    const int v = lane & 3;
+    const double cx = v == 0 ? verts[0][0] : v == 1 ? verts[1][0] : v == 2 ? verts[2][0] : verts[3][0];
+    const double cy = v == 0 ? verts[0][1] : v == 1 ? verts[1][1] : v == 2 ? verts[2][1] : verts[3][1];
+    const double vx = cx - px, vy = cy - py;
+    const double norm = sqrt(vx * vx + vy * vy);
+    const double ux = vx / norm, uy = vy / norm;
+    double angle = ego_ang - atan2(uy, ux);
+    if (angle > F110_PI) angle = angle - 2 * F110_PI;
+    else if (angle < -F110_PI) angle = angle + 2 * F110_PI;
+    const int ind = argmin_abs_diff_sorted(scan_angles, nb, -angle);
+    int lo = ind, hi = ind;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        double vx = verts[i][0] - px, vy = verts[i][1] - py;
-        double norm = sqrt(vx * vx + vy * vy);
-        double ux = vx / norm, uy = vy / norm;
-        double angle = ego_ang - atan2(uy, ux);
-        if (angle > F110_PI) angle = angle - 2 * F110_PI;
-        else if (angle < -F110_PI) angle = angle + 2 * F110_PI;
-        int ind = wave_argmin_abs_diff(scan_angles, nb, -angle, lane);
-        if (i == 0) { lo = hi = ind; }
-        else { lo = ind < lo ? ind : lo; hi = ind > hi ? ind : hi; }
+    for (int off = 1; off <= 2; off <<= 1) {
+        const int o_lo = __shfl_xor(lo, off), o_hi = __shfl_xor(hi, off);
+        lo = o_lo < lo ? o_lo : lo;
+        hi = o_hi > hi ? o_hi : hi;
     }
     min_ind = lo;
     max_ind = hi;

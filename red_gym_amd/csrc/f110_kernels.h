@@ -161,12 +161,14 @@ struct ScanArgs {
     ScanDev scan;
     int n_cars;
     int agents;             // A (cars of one env are consecutive)
+    int wpc;                // wavefronts per car (power of two): small batches split a car's beams over
+                            // several waves so that the chip is still filled; chunk position p goes to wave p % wpc
     // pose source: pose = (src[car*stride], src[car*stride+1], src[car*stride+yaw_off])
     const double *pose_src;
     int pose_stride, yaw_off;
     // full-step extras (all NULL for the function-level scan)
-    double *state;               // [N,7]: read vel, zero state[3:] on iTTC hit
-    int32_t *noise_step;         // [N]
+    const double *state;         // [N,7]: velocity for the iTTC test
+    const int32_t *noise_step;   // [N]
     const double *noise;         // [T,nb] or NULL
     long long noise_T;
     const double *beam_cosines, *side_distances; // [nb]
@@ -208,8 +210,15 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
     mv.init(a.map);
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int car = blockIdx.x * SCAN_WAVES + wave; // wave-uniform (scalar)
+    const int wid = blockIdx.x * SCAN_WAVES + wave; // wave-uniform (scalar)
+    const int wpc = a.wpc;
+    const int car = wid / wpc, part = wid % wpc;
     if (car >= a.n_cars) return;
+    // this wave's slice of the car's beam queue: chunk positions part, part+wpc, ...
+    const int nch = (nb + 63) >> 6;
+    const int my_chunks = nch > part ? (nch - part + wpc - 1) / wpc : 0;
+    const int owns_last = my_chunks > 0 && ((nch - 1) % wpc) == part;
+    const int nbl = my_chunks * 64 - (owns_last ? nch * 64 - nb : 0); // beams of this wave
     if (a.reset_only && !a.pending_reset[car / a.agents]) return;
 
     const double px = a.pose_src[(size_t)car * a.pose_stride];
@@ -218,8 +227,7 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
     const double eps = a.scan.eps, max_range = a.scan.max_range;
 
     // per-car constants of the finishing stage
-    double *st = STEP ? a.state + (size_t)car * 7 : nullptr;
-    const double vel = STEP ? st[3] : 0.0;
+    const double vel = STEP ? a.state[(size_t)car * 7 + 3] : 0.0;
     const bool do_ttc = STEP && vel != 0.0;               // laser_models.py:206
     // iTTC hit needs 0 <= (v - side)/(vel*cos) < thresh, hence |v - side| < thresh*|vel|:
     // only such candidate beams pay the exact fp64 division
@@ -251,9 +259,12 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
     // ---- ray march (laser_models.py:107-186) -------------------------------------
     // The first table read of every beam is at the car itself (:129): done once.
     const double d0 = dist_lookup<IDENT, POW2>(mv, s_lut, px, py, true);
-    unsigned nlook = (unsigned)nb; // the reference reads the table once per beam before marching
+    unsigned nlook = (unsigned)nbl; // the reference reads the table once per beam before marching
     if (!(d0 > eps && d0 <= max_range)) {
-        for (int i = lane; i < nb; i += WAVE) emit(i, d0, STEP ? nz[i] : 0.0, STEP ? side[i] : 0.0);
+        for (int k = lane; k < nbl; k += WAVE) {
+            const int i = s_chunk0[(k >> 6) * wpc + part] + (k & 63);
+            emit(i, d0, STEP ? nz[i] : 0.0, STEP ? side[i] : 0.0);
+        }
     } else {
         const double td = (double)a.scan.theta_dis;
         double t0w = td * (yaw - a.scan.fov / 2.) / (2. * F110_PI);
@@ -277,9 +288,9 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
                 const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32),
                                     __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
                 const int k = next + rank;
-                const bool take = k < nb;
+                const bool take = k < nbl;
                 const int kk = take ? k : 0;
-                const int b = s_chunk0[kk >> 6] + (kk & 63);
+                const int b = s_chunk0[(kk >> 6) * wpc + part] + (kk & 63);
                 const int ti = beam_theta_index(t0w, b, a.scan);
                 const double2 cs = a.scan.cs[ti]; // second round trip, overlapped with emit()
                 if (beam >= 0) emit(beam, total, nzv, sdv);
@@ -302,7 +313,7 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
             if (nact == 0) break;
             // ---- march phase: every lane steps (idle lanes are parked by d = 0) until
             // enough lanes are idle again or, once no beams are left, the wave has drained ----
-            const int go = next < nb ? WAVE - REFILL_MIN_IDLE : 0; // keep marching while nact > go
+            const int go = next < nbl ? WAVE - REFILL_MIN_IDLE : 0; // keep marching while nact > go
             do {
 #if !defined(F110_COUNT_MODE)
                 nlook += (unsigned)nact;
@@ -326,16 +337,12 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
             } while (nact > go);
         }
     }
-    if (a.lookups && lane == 0) a.lookups[car] += nlook;
+    if (a.lookups && lane == 0) atomicAdd(&a.lookups[car], nlook);
 
-    // ---- iTTC result (base_classes.py:241-250) ------------------------------------
+    // ---- iTTC result: the flag only; env_kernel zeroes the state (base_classes.py:241-250)
+    // once every wave of the car is done.  Plain store: all writers store the same 1.
     if (STEP) {
-        const bool any_hit = vote(hit) != 0ull;
-        if (lane == 0) {
-            if (any_hit) { st[3] = 0.; st[4] = 0.; st[5] = 0.; st[6] = 0.; }
-            a.in_collision[car] = any_hit ? 1 : 0;
-            a.noise_step[car] += 1;
-        }
+        if (vote(hit) != 0ull && lane == 0) a.in_collision[car] = 1;
     }
 }
 
@@ -347,6 +354,7 @@ struct OppArgs {
     int n_cars, agents, nb;
     const double *state;      // [N,7]
     const double *pose_snap;  // [N,3]
+    const uint8_t *in_collision; // [N]
     const double *scan_angles;
     double car_length, car_width;
     const uint8_t *pending_reset;
@@ -362,7 +370,8 @@ __global__ __launch_bounds__(256) void opponents_kernel(OppArgs a)
     const int env = car / a.agents;
     if (a.reset_only && !a.pending_reset[env]) return;
     const double *st = a.state + (size_t)car * 7;
-    const double px = st[0], py = st[1], pyaw = st[4];
+    // an iTTC hit zeroes the yaw before the ray cast (base_classes.py:245); env_kernel applies it
+    const double px = st[0], py = st[1], pyaw = a.in_collision[car] ? 0.0 : st[4];
     const int a0 = env * a.agents;
     for (int j = 0; j < a.agents; j++) {
         if (a0 + j == car) continue;
@@ -387,6 +396,7 @@ struct DynArgs {
     const uint8_t *pending_reset; // [B] or NULL
     int reset_only;
     double *pose_snap;    // [N,3] or NULL
+    uint8_t *in_collision;// [N] or NULL: cleared here, set by scan_kernel
     Params params;
     double time_step;
     int integrator;
@@ -430,6 +440,7 @@ __global__ __launch_bounds__(256) void dynamics_kernel(DynArgs a)
     a.steer_buf[(size_t)car * 2] = sb[0];
     a.steer_buf[(size_t)car * 2 + 1] = sb[1];
     a.steer_cnt[car] = sc;
+    if (a.in_collision) a.in_collision[car] = 0;
     if (a.pose_snap) {
         a.pose_snap[(size_t)car * 3] = st[0];
         a.pose_snap[(size_t)car * 3 + 1] = st[1];
@@ -440,7 +451,8 @@ __global__ __launch_bounds__(256) void dynamics_kernel(DynArgs a)
 // ------------------------------------------------------------------ env bookkeeping (lane per env)
 struct EnvArgs {
     int n_envs, agents, ego_idx, autoreset, reset_only;
-    const double *state;      // [N,7] (after iTTC zeroing)
+    double *state;            // [N,7]: state[3:] zeroed here on an iTTC hit
+    int32_t *noise_step;      // [N]: one noise row consumed per scan
     const double *pose_snap;  // [N,3]
     const double *spawn;      // [N,3]
     const uint8_t *in_collision; // [N]
@@ -454,6 +466,7 @@ struct EnvArgs {
     double *current_time;     // [B]
     uint8_t *pending_reset;   // [B]
     uint8_t *done;            // [B]
+    uint8_t *checkpoint_done; // [N] or NULL
     double time_step, car_length, car_width;
 };
 
@@ -486,8 +499,14 @@ __global__ __launch_bounds__(128) void env_kernel(EnvArgs a)
     // Simulator.check_collision (base_classes.py:529-543) on the post-integration poses
     collision_multiple_dev(a.pose_snap + (size_t)c0 * 3, A, a.car_length, a.car_width,
                            a.collisions + c0, a.collision_idx + c0);
-    for (int i = 0; i < A; i++)
-        if (a.in_collision[c0 + i]) a.collisions[c0 + i] = 1; // :581-582
+    for (int i = 0; i < A; i++) {
+        if (a.in_collision[c0 + i]) {
+            a.collisions[c0 + i] = 1; // :581-582
+            double *st = a.state + (size_t)(c0 + i) * 7; // check_ttc, base_classes.py:244-247
+            st[3] = 0.; st[4] = 0.; st[5] = 0.; st[6] = 0.;
+        }
+        a.noise_step[c0 + i] += 1;
+    }
     double ct = a.current_time[env];
     double r00, r01, r10, r11;
     if (pend) {
@@ -527,6 +546,7 @@ __global__ __launch_bounds__(128) void env_kernel(EnvArgs a)
         a.toggles[car] = tg;
         a.lap_counts[car] = tg / 2;
         if (tg < 4) a.lap_times[car] = ct;
+        if (a.checkpoint_done) a.checkpoint_done[car] = tg >= 4 ? 1 : 0;
         if (!(tg >= 4)) all_done = false;
     }
     const bool dn = (a.collisions[c0 + a.ego_idx] != 0) || all_done;

@@ -20,7 +20,7 @@ _TORCH_DTYPES = {
     'current_time': torch.float64, 'pending_reset': torch.uint8, 'scans': torch.float32,
     'scans_f64': torch.float64, 'pose_snap': torch.float64, 'collisions': torch.uint8,
     'collision_idx': torch.int32, 'in_collision': torch.uint8, 'lap_counts': torch.int32,
-    'lap_times': torch.float64, 'done': torch.uint8, 'lookups': torch.int32,
+    'lap_times': torch.float64, 'done': torch.bool, 'checkpoint_done': torch.bool, 'lookups': torch.int32,
 }
 
 
@@ -131,7 +131,7 @@ class Engine(object):
                   'spawn': (B, A, 3), 'start_rot': (B, 4), 'near_start': (B, A), 'toggles': (B, A),
                   'current_time': (B,), 'pending_reset': (B,), 'scans': (B, A, nb), 'scans_f64': (B, A, nb),
                   'pose_snap': (B, A, 3), 'collisions': (B, A), 'collision_idx': (B, A), 'in_collision': (B, A),
-                  'lap_counts': (B, A), 'lap_times': (B, A), 'done': (B,), 'lookups': (B, A)}
+                  'lap_counts': (B, A), 'lap_times': (B, A), 'done': (B,), 'checkpoint_done': (B, A), 'lookups': (B, A)}
         self.t = {}
         bufs = _lib.Buffers()
         for name in _lib.BUFFER_FIELDS:

@@ -57,8 +57,8 @@ class F110VecEnv(object):
 
     def _result(self):
         t = self.eng.t
-        done = t['done'].bool()
-        info = {'checkpoint_done': t['toggles'] >= 4, 'collision_idx': t['collision_idx'],
+        done = t['done']  # bool tensor written by env_kernel (no per-step torch kernels here)
+        info = {'checkpoint_done': t['checkpoint_done'], 'collision_idx': t['collision_idx'],
                 'current_time': t['current_time'], 'toggles': t['toggles']}
         return self._obs, self._reward, done, info
 
