@@ -44,6 +44,7 @@ struct f110_handle {
     double *d_scan_angles = nullptr, *d_beam_cosines = nullptr, *d_side = nullptr;
     uint16_t *d_cells = nullptr, *d_chunk0 = nullptr;
     double2 *d_cs = nullptr;          // interleaved {cos, sin} LUT
+    double2 *d_beam_cs = nullptr;     // {cos, sin}(scan_angles) for the opponent ray cast
     double *d_zero_row = nullptr;     // noise row used when noise is off
     std::vector<double> h_sines, h_cosines;
     double *d_lut = nullptr, *d_dt = nullptr;
@@ -191,6 +192,17 @@ static int set_beam_order(f110_handle *h)
     return F110_OK;
 }
 
+// {cos, sin} of the beam angles (libm), used by the opponent ray cast's angle addition.
+static int upload_beam_cs(f110_handle *h, const double *scan_angles)
+{
+    const int n = h->cfg.num_beams;
+    std::vector<double2> cs(n);
+    for (int i = 0; i < n; i++) { cs[i].x = std::cos(scan_angles[i]); cs[i].y = std::sin(scan_angles[i]); }
+    if (!h->d_beam_cs) HIP_TRY(hipMalloc((void **)&h->d_beam_cs, n * sizeof(double2)));
+    HIP_TRY(hipMemcpy(h->d_beam_cs, cs.data(), n * sizeof(double2), hipMemcpyHostToDevice));
+    return F110_OK;
+}
+
 // (Re)builds the interleaved {cos, sin} device table from the host copies.
 static int upload_cs(f110_handle *h)
 {
@@ -235,7 +247,7 @@ extern "C" int f110_create(const f110_config *cfg, f110_handle **out)
     h->h_cosines = c;
     std::vector<double> zeros(cfg->num_beams, 0.0);
     if ((rc = upload_cs(h)) || (rc = upload(&h->d_zero_row, zeros.data(), zeros.size())) ||
-        (rc = upload(&h->d_scan_angles, ang.data(), ang.size())) ||
+        (rc = upload(&h->d_scan_angles, ang.data(), ang.size())) || (rc = upload_beam_cs(h, ang.data())) ||
         (rc = upload(&h->d_beam_cosines, bcos.data(), bcos.size())) ||
         (rc = upload(&h->d_side, side.data(), side.size())) || (rc = set_beam_order(h))) {
         f110_destroy(h);
@@ -249,7 +261,7 @@ extern "C" void f110_destroy(f110_handle *h)
 {
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
-    void *ptrs[] = {h->d_cs, h->d_zero_row, h->d_scan_angles, h->d_beam_cosines, h->d_side,
+    void *ptrs[] = {h->d_cs, h->d_beam_cs, h->d_zero_row, h->d_scan_angles, h->d_beam_cosines, h->d_side,
                     h->d_cells, h->d_lut, h->d_dt, h->d_noise, h->d_chunk0};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -274,7 +286,7 @@ extern "C" int f110_set_tables(f110_handle *h, const double *sines, const double
     if (sines) h->h_sines.assign(sines, sines + h->cfg.theta_dis);
     if (cosines) h->h_cosines.assign(cosines, cosines + h->cfg.theta_dis);
     if ((sines || cosines) && (rc = upload_cs(h))) return rc;
-    if (ang && (rc = upload(&h->d_scan_angles, ang, h->cfg.num_beams))) return rc;
+    if (ang && ((rc = upload(&h->d_scan_angles, ang, h->cfg.num_beams)) || (rc = upload_beam_cs(h, ang)))) return rc;
     if (bcos && (rc = upload(&h->d_beam_cosines, bcos, h->cfg.num_beams))) return rc;
     if (side && (rc = upload(&h->d_side, side, h->cfg.num_beams))) return rc;
     return rc;
@@ -481,7 +493,7 @@ static int run_step(f110_handle *h, const double *actions, int reset_only, hipSt
     if (c.num_agents > 1) {
         OppArgs o;
         o.n_cars = N; o.agents = c.num_agents; o.nb = c.num_beams; o.state = b.state; o.pose_snap = b.pose_snap;
-        o.in_collision = b.in_collision; o.scan_angles = h->d_scan_angles; o.car_length = h->params.v[P_LENGTH]; o.car_width = h->params.v[P_WIDTH];
+        o.in_collision = b.in_collision; o.scan_angles = h->d_scan_angles; o.beam_cs = h->d_beam_cs; o.car_length = h->params.v[P_LENGTH]; o.car_width = h->params.v[P_WIDTH];
         o.pending_reset = b.pending_reset; o.reset_only = reset_only; o.scans32 = b.scans; o.scans64 = b.scans_f64;
         hipLaunchKernelGGL(opponents_kernel, dim3((N + 3) / 4), dim3(256), 0, st, o);
         HIP_TRY(hipGetLastError());
@@ -654,7 +666,7 @@ extern "C" int f110_ray_cast(f110_handle *h, const double *ego, const double *ve
     if (h && n == 0) return F110_OK;
     if (!h || !ego || !verts || !scans || n < 0) return fail(F110_E_INVALID, "f110_ray_cast: bad arguments");
     hipLaunchKernelGGL(ray_cast_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, ego, verts, n,
-                       h->cfg.num_beams, h->d_scan_angles, scans, span);
+                       h->cfg.num_beams, h->d_scan_angles, h->d_beam_cs, scans, span);
     HIP_TRY(hipGetLastError());
     return F110_OK;
 }

@@ -356,6 +356,7 @@ struct OppArgs {
     const double *pose_snap;  // [N,3]
     const uint8_t *in_collision; // [N]
     const double *scan_angles;
+    const double2 *beam_cs;   // [nb] {cos, sin}(scan_angles)
     double car_length, car_width;
     const uint8_t *pending_reset;
     int reset_only;
@@ -363,7 +364,10 @@ struct OppArgs {
     double *scans64;          // [N,nb] or NULL
 };
 
-__global__ __launch_bounds__(256) void opponents_kernel(OppArgs a)
+#ifndef F110_OPP_MIN_WAVES
+#define F110_OPP_MIN_WAVES 1
+#endif
+__global__ __launch_bounds__(256, F110_OPP_MIN_WAVES) void opponents_kernel(OppArgs a)
 {
     const int car = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (car >= a.n_cars) return;
@@ -378,7 +382,7 @@ __global__ __launch_bounds__(256) void opponents_kernel(OppArgs a)
         const double *op = a.pose_snap + (size_t)(a0 + j) * 3;
         double verts[4][2];
         get_vertices(op[0], op[1], op[2], a.car_length, a.car_width, verts);
-        ray_cast_wave(px, py, pyaw, verts, a.scan_angles, a.nb, lane,
+        ray_cast_wave(px, py, pyaw, verts, a.scan_angles, a.beam_cs, a.nb, lane,
                       a.scans64 ? a.scans64 + (size_t)car * a.nb : nullptr,
                       a.scans32 ? a.scans32 + (size_t)car * a.nb : nullptr, nullptr);
     }
@@ -616,13 +620,14 @@ __global__ void ttc_kernel(const double *scans, const double *vel, int n, int nb
 
 // ray_cast (laser_models.py:319-346): wave per (ego, opponent quad)
 __global__ void ray_cast_kernel(const double *ego, const double *verts, int n, int nb, const double *scan_angles,
+                                const double2 *beam_cs,
                                 double *scans, int32_t *span)
 {
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= n) return;
     double v[4][2];
     for (int k = 0; k < 4; k++) { v[k][0] = verts[(size_t)row * 8 + 2 * k]; v[k][1] = verts[(size_t)row * 8 + 2 * k + 1]; }
-    ray_cast_wave(ego[3 * row], ego[3 * row + 1], ego[3 * row + 2], v, scan_angles, nb, lane,
+    ray_cast_wave(ego[3 * row], ego[3 * row + 1], ego[3 * row + 2], v, scan_angles, beam_cs, nb, lane,
                   scans + (size_t)row * nb, nullptr, span ? span + 2 * row : nullptr);
 }
 
