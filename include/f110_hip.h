@@ -150,6 +150,15 @@ int f110_step(f110_handle *h, const double *actions_dev, void *stream);
 int f110_profile_begin(f110_handle *h, int32_t max_launches);
 int f110_profile_end(f110_handle *h, double *scan_ms_total, int32_t *launches);
 
+/* Batched pure-pursuit planner, the caller on the other side of F110Env.step
+ * (examples/waypoint_follow.py:15-217: nearest point on the raceline, first intersection
+ * of the lookahead circle with the polyline incl. wrap-around, actuation).  waypoints:
+ * dev [M,3] (x, y, speed); state: dev [n,7] (f110_buffers.state); writes actions dev [n,2]
+ * = (steer, vgain*speed), ready to be passed to f110_step. */
+int f110_pure_pursuit(f110_handle *h, const double *waypoints, int32_t M, double lookahead, double vgain,
+                      double wheelbase, double max_reacquire, const double *state, int32_t n,
+                      double *actions, void *stream);
+
 /* ---- function-level entry points (parity tests; all pointers dev) ---- */
 /* ScanSimulator2D.scan(pose, None): n poses [n,3] -> [n,num_beams] (noise off).
  * scans_f32 / lookups may be NULL; lookups [n] is overwritten-by-accumulation like

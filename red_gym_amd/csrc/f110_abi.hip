@@ -4,6 +4,7 @@
 // synchronisation inside f110_step / f110_reset.
 #include "../../include/f110_hip.h"
 #include "f110_kernels.h"
+#include "f110_planner.h"
 
 #include <algorithm>
 #include <cmath>
@@ -585,6 +586,27 @@ extern "C" int f110_profile_end(f110_handle *h, double *ms_total, int32_t *launc
     *ms_total = tot;
     *launches = h->prof_n;
     prof_clear(h);
+    return F110_OK;
+}
+
+// ---------------------------------------------------------------- planner
+extern "C" int f110_pure_pursuit(f110_handle *h, const double *waypoints, int32_t M, double lookahead, double vgain,
+                                 double wheelbase, double max_reacquire, const double *state, int32_t n,
+                                 double *actions, void *stream)
+{
+    if (!h || n < 0) return fail(F110_E_INVALID, "f110_pure_pursuit: bad arguments");
+    if (n == 0) return F110_OK;
+    if (!waypoints || !state || !actions) return fail(F110_E_INVALID, "f110_pure_pursuit: null pointer");
+    if (M < 2 || (size_t)M * 3 * sizeof(double) > 150 * 1024)
+        return fail(F110_E_INVALID, "f110_pure_pursuit: M=%d waypoints (2..6400: the raceline is staged in LDS)", M);
+    PlanArgs a;
+    a.waypoints = waypoints; a.M = M; a.lookahead = lookahead; a.vgain = vgain; a.wheelbase = wheelbase;
+    a.max_reacquire = max_reacquire; a.state = state; a.n = n; a.actions = actions;
+    const size_t smem = (size_t)M * 3 * sizeof(double);
+    if (smem > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void *)pure_pursuit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL(pure_pursuit_kernel, dim3((n + 255) / 256), dim3(256), smem, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
     return F110_OK;
 }
 

@@ -285,6 +285,22 @@ class Engine(object):
                                           self._stream()))
         return scans, span
 
+    # ------------------------------------------------------------------ planner
+    def pure_pursuit(self, waypoints, lookahead, vgain, wheelbase=0.17145 + 0.15875, max_reacquire=20.,
+                     state=None, out=None):
+        """waypoints: [M,3] (x, y, speed) device tensor; returns actions [B,A,2] (steer, speed)
+        planned from the current state -- feed it straight to step()."""
+        st = self.t['state'] if state is None else self._dev64(state, (-1, 7))
+        n = st.numel() // 7
+        if out is None:
+            out = torch.empty((n, 2), dtype=torch.float64, device=self.device)
+        waypoints = self._dev64(waypoints, (-1, 3))
+        _lib.check(self.lib.f110_pure_pursuit(self._h, _ptr(waypoints), waypoints.shape[0], float(lookahead),
+                                              float(vgain), float(wheelbase), float(max_reacquire), _ptr(st), n,
+                                              _ptr(out), self._stream()))
+        self._keep_wp = waypoints
+        return out.view(self.B, self.A, 2) if state is None else out
+
     # ------------------------------------------------------------------ measurement aid
     def profile_begin(self, max_launches):
         _lib.check(self.lib.f110_profile_begin(self._h, int(max_launches)))

@@ -88,6 +88,13 @@ class F110VecEnv(object):
         self.eng.step(self._as_dev(actions, 2))
         return self._result()
 
+    def pure_pursuit(self, waypoints, lookahead, vgain, wheelbase=0.17145 + 0.15875):
+        """Batched pure-pursuit actions for the current poses (examples/waypoint_follow.py planner
+        on the GPU); waypoints [M,3] = (x, y, speed)."""
+        if not torch.is_tensor(waypoints) or waypoints.device != self.device:
+            waypoints = torch.as_tensor(np.ascontiguousarray(waypoints, dtype=np.float64), device=self.device)
+        return self.eng.pure_pursuit(waypoints, lookahead, vgain, wheelbase)
+
     def update_params(self, params, index=-1):
         """base_classes.py:507-527; all cars of a batch share one parameter set."""
         if index >= self.num_agents:

@@ -79,3 +79,47 @@ def test_f110env_kwargs_and_errors(assets):
     assert obs['linear_vels_y'] == [0., 0.] and r == 0.01
     env.render()  # accepted, no-op
     env.close()
+
+
+def test_hip_pure_pursuit_matches_numpy_planner(assets):
+    """batched pure pursuit on the GPU vs the NumPy restatement of
+    examples/waypoint_follow.py:15-217 (which reproduces the reference's recorded actions)."""
+    from argparse import Namespace
+    import yaml
+    from red_gym_amd import F110VecEnv, workload
+    from red_gym_amd.planners import PurePursuitPlanner
+    conf = Namespace(**yaml.safe_load(open(os.path.join(assets, 'config_example_map.yaml'))))
+    conf.wpt_path = os.path.join(assets, 'example_waypoints.csv')
+    pl = PurePursuitPlanner(conf, 0.17145 + 0.15875)
+    wp = np.stack([pl.waypoints[:, conf.wpt_xind], pl.waypoints[:, conf.wpt_yind], pl.waypoints[:, conf.wpt_vind]], axis=1)
+    B = 512
+    env = F110VecEnv(B, map=workload.EXAMPLE_MAP, num_agents=1, autoreset=False)
+    rng = np.random.default_rng(4)
+    poses = workload.spawn_poses(B, 1)
+    poses[:64, 0, :2] += rng.normal(0, 1.0, (64, 2))     # off the raceline (> lookahead: re-acquire branch)
+    poses[64:72, 0, :2] += 100.0                         # farther than max_reacquire: (4.0, 0.0)
+    poses[72:80, 0, :] = [wp[-1, 0], wp[-1, 1], 1.0]     # at the last waypoint: wrap-around search
+    env.reset(poses)
+    tlad, vgain = 0.82461887897713965, 1.375
+    act = env.pure_pursuit(wp, tlad, vgain).cpu().numpy()
+    st = env.state.cpu().numpy()
+    for b in range(B):
+        sp, stg = pl.plan(st[b, 0, 0], st[b, 0, 1], st[b, 0, 4], tlad, vgain)
+        assert abs(act[b, 0, 0] - stg) < 1e-12 and abs(act[b, 0, 1] - sp) < 1e-12, b
+    assert (act[64:72, 0, 1] == 4.0).all() and (act[64:72, 0, 0] == 0.0).all()
+    # closed loop on the GPU: 16 cars race 400 steps without touching the host planner
+    env2 = F110VecEnv(16, map=workload.EXAMPLE_MAP, num_agents=1, autoreset=False, keep_f64_scans=True)
+    p2 = np.repeat(np.array([[[conf.sx, conf.sy, conf.stheta]]]), 16, axis=0)
+    env2.reset(p2)
+    sc = oracle.Scanner(1080, 2 * np.pi)
+    sc.set_map(workload.EXAMPLE_MAP + '.yaml', '.png')
+    oenv = oracle.Env(sc, 1, noise=oracle.noise_table(12345, 402))
+    oo = oenv.reset(p2[0])
+    for k in range(400):
+        env2.step(env2.pure_pursuit(wp, tlad, vgain))
+        sp, stg = pl.plan(oo['state'][0, 0], oo['state'][0, 1], oo['state'][0, 4], tlad, vgain)
+        oo = oenv.step(np.array([[stg, sp]]))
+    s = env2.state.cpu().numpy()
+    assert np.allclose(s[0, 0], oo['state'][0], rtol=0, atol=1e-7) and np.array_equal(s[0], s[15])
+    assert s[0, 0, 3] > 5.0  # racing, not crashed
+    env.close(); env2.close()
