@@ -44,7 +44,8 @@ struct f110_handle {
     // device tables owned by the handle
     double *d_scan_angles = nullptr, *d_beam_cosines = nullptr, *d_side = nullptr;
     uint16_t *d_cells = nullptr, *d_chunk0 = nullptr;
-    double2 *d_cs = nullptr;          // interleaved {cos, sin} LUT
+    double2 *d_cs = nullptr;          // interleaved {cos, sin} LUT (repeated, see upload_cs)
+    int cs_len = 0;
     double2 *d_beam_cs = nullptr;     // {cos, sin}(scan_angles) for the opponent ray cast
     double *d_zero_row = nullptr;     // noise row used when noise is off
     std::vector<double> h_sines, h_cosines;
@@ -207,11 +208,17 @@ static int upload_beam_cs(f110_handle *h, const double *scan_angles)
 // (Re)builds the interleaved {cos, sin} device table from the host copies.
 static int upload_cs(f110_handle *h)
 {
-    const int n = h->cfg.theta_dis;
+    // repeated so that an un-wrapped index theta_index + b*increment stays inside:
+    // start < theta_dis, span <= fov/(2 pi) * theta_dis * nb/(nb-1)
+    const int td = h->cfg.theta_dis;
+    const int reps = 2 + (int)std::ceil(std::fabs(h->cfg.fov) / (2 * F110_PI) * h->cfg.num_beams / (h->cfg.num_beams - 1.0));
+    const int n = td * reps;
     std::vector<double2> cs(n);
-    for (int i = 0; i < n; i++) { cs[i].x = h->h_cosines[i]; cs[i].y = h->h_sines[i]; }
+    for (int i = 0; i < n; i++) { cs[i].x = h->h_cosines[i % td]; cs[i].y = h->h_sines[i % td]; }
+    if (h->d_cs && h->cs_len != n) { (void)hipFree(h->d_cs); h->d_cs = nullptr; }
     if (!h->d_cs) HIP_TRY(hipMalloc((void **)&h->d_cs, n * sizeof(double2)));
     HIP_TRY(hipMemcpy(h->d_cs, cs.data(), n * sizeof(double2), hipMemcpyHostToDevice));
+    h->cs_len = n;
     return F110_OK;
 }
 
@@ -424,7 +431,7 @@ static ScanDev scan_dev(const f110_handle *h)
 {
     ScanDev s;
     s.nb = h->cfg.num_beams; s.theta_dis = h->cfg.theta_dis; s.fov = h->cfg.fov; s.eps = h->cfg.eps;
-    s.max_range = h->cfg.max_range; s.inc = h->theta_inc; s.inv_td = 1.0 / h->cfg.theta_dis; s.cs = h->d_cs;
+    s.max_range = h->cfg.max_range; s.inc = h->theta_inc; s.inc_fx = (unsigned long long)std::llround(h->theta_inc * 1099511627776.0); s.cs_len = h->cs_len; s.cs = h->d_cs;
     return s;
 }
 

@@ -79,8 +79,9 @@ struct MapView {
 struct ScanDev {
     int nb, theta_dis;
     double fov, eps, max_range, inc; // inc = theta_index_increment (laser_models.py:368)
-    double inv_td;                   // 1 / theta_dis
-    const double2 *cs;               // [theta_dis] {cos, sin} of the LUT angles (laser_models.py:379-381)
+    unsigned long long inc_fx;       // inc in 24.40 fixed point
+    int cs_len;                      // entries of cs (theta_dis * repetitions)
+    const double2 *cs;               // [cs_len] {cos, sin} of the LUT angles (laser_models.py:379-381), repeated
 };
 
 // laser_models.py:56-104: (x, y) -> distance-table value, branch-free.  IDENT: origin
@@ -134,18 +135,22 @@ __device__ inline double dist_lookup(const MapView &m, const double *lds_lut, do
     return d;
 }
 
-// laser_models.py:167-184: LUT index of beam b.  The reference advances
-// theta_index by 1080 sequential fp64 adds; t0w + b*inc differs from that by
-// < 3e-10, so the truncation agrees unless the value is within 1e-8 of an
-// integer -- then this lane replays the recurrence exactly.
-__device__ inline int beam_theta_index(double t0w, int b, const ScanDev &s)
+// laser_models.py:167-184: LUT index of beam b.  The reference advances theta_index by
+// num_beams sequential fp64 adds (wrapping at theta_dis); in 24.40 fixed point
+// T0 + b*INC differs from that recurrence by < 1e-9, so the integer part agrees unless
+// the fraction is within 1e-7 of 0 or 1 -- then this lane replays the recurrence exactly.
+// The index is NOT wrapped: the {cos, sin} table is stored `cs_reps` times back to back
+// (wrapping subtracts theta_dis exactly, so entry idx and idx - theta_dis are the same).
+__device__ inline int beam_theta_index(unsigned long long T0, double t0w, int b, const ScanDev &s)
 {
-    const double td = (double)s.theta_dis;
-    double t = t0w + (double)b * s.inc;
-    t -= floor(t * s.inv_td) * td; // any error lands in the guard band below
-    int idx = (int)t;
-    double fr = t - (double)idx;
-    if (__builtin_expect(!(fr > 1e-8 && fr < 1. - 1e-8) || idx < 0 || idx >= s.theta_dis, 0)) {
+    const unsigned inc_lo = (unsigned)s.inc_fx, inc_hi = (unsigned)(s.inc_fx >> 32);
+    unsigned long long t = (unsigned long long)(unsigned)b * inc_lo + T0;    // v_mad_u64_u32
+    unsigned hi = (unsigned)(t >> 32) + (unsigned)b * inc_hi;                // inc_hi, b < 2^24
+    const unsigned lo = (unsigned)t;
+    int idx = (int)(hi >> 8);
+    const unsigned frac = __builtin_amdgcn_alignbit(hi, lo, 8);             // top 32 fraction bits
+    if (__builtin_expect(frac + 430u < 860u || idx >= s.cs_len, 0)) {        // within 1e-7 of an integer
+        const double td = (double)s.theta_dis;
         double tt = t0w;
         for (int j = 0; j < b; j++) {
             tt += s.inc;
@@ -242,10 +247,10 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
     // stores, iTTC (:189-217).  nzv / sdv: noise and side distance of the beam, loaded by
     // the caller ahead of time.
     auto emit = [&](int i, double tot, double nzv, double sdv) {
-        double v = tot > max_range ? max_range : tot;
+        double v = __builtin_fmin(tot, max_range); // :143-144 (a NaN total, i.e. a NaN pose, also clamps)
         if (STEP) v += nzv;
-        if (o32) o32[i] = (float)v;
-        if (o64) o64[i] = v;
+        if (o32) *reinterpret_cast<float *>(reinterpret_cast<char *>(o32) + (size_t)((unsigned)i * 4u)) = (float)v;
+        if (o64) *reinterpret_cast<double *>(reinterpret_cast<char *>(o64) + (size_t)((unsigned)i * 8u)) = v;
         if (do_ttc) {
             const double sd = v - sdv;
             if (__builtin_expect(fabs(sd) < cand, 0)) {
@@ -270,6 +275,8 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
         double t0w = td * (yaw - a.scan.fov / 2.) / (2. * F110_PI);
         t0w = fmod(t0w, td);
         while (t0w < 0) t0w += td;
+        // 24.40 fixed point of t0w in [0, theta_dis); a NaN / out-of-range yaw falls to the slow path
+        const unsigned long long T0 = (t0w >= 0 && t0w < td) ? (unsigned long long)(t0w * 1099511627776.0) : ~0ull;
 
         int next = 0;           // wave-uniform: next unassigned slot of the beam order
         bool active = false;
@@ -282,17 +289,17 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
             if (!active) {
                 // all independent loads first (one memory round trip): the finished beam's
                 // noise / side distance and the new beam's number
-                const int pb = beam < 0 ? 0 : beam;
-                const double nzv = STEP ? nz[pb] : 0.0;
-                const double sdv = STEP ? side[pb] : 0.0;
+                const unsigned pb8 = (unsigned)(beam < 0 ? 0 : beam) * 8u; // 32-bit byte offset: scalar base + VGPR offset
+                const double nzv = STEP ? *reinterpret_cast<const double *>(reinterpret_cast<const char *>(nz) + (size_t)pb8) : 0.0;
+                const double sdv = STEP ? *reinterpret_cast<const double *>(reinterpret_cast<const char *>(side) + (size_t)pb8) : 0.0;
                 const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32),
                                     __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
                 const int k = next + rank;
                 const bool take = k < nbl;
                 const int kk = take ? k : 0;
                 const int b = s_chunk0[(kk >> 6) * wpc + part] + (kk & 63);
-                const int ti = beam_theta_index(t0w, b, a.scan);
-                const double2 cs = a.scan.cs[ti]; // second round trip, overlapped with emit()
+                const int ti = beam_theta_index(T0, t0w, b, a.scan);
+                const double2 cs = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(a.scan.cs) + (size_t)((unsigned)ti * 16u)); // second round trip, overlapped with emit()
                 if (beam >= 0) emit(beam, total, nzv, sdv);
                 beam = -1;
                 if (take) {
