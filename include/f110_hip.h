@@ -97,8 +97,12 @@ int f110_create(const f110_config *cfg, f110_handle **out);
 void f110_destroy(f110_handle *h);
 const char *f110_last_error(void);
 
-/* Simulator.update_params (base_classes.py:507-527): params shared by all cars. */
-int f110_update_params(f110_handle *h, const double *params18_host);
+/* Simulator.update_params (base_classes.py:507-527): agent_idx < 0 updates every agent,
+ * otherwise agent `agent_idx` of every env (F110_E_INDEX if >= num_agents).  As in the
+ * reference this changes the cars' dynamics and the size they attribute to opponents
+ * (base_classes.py:221), not the Simulator's own copy used by the GJK check (:542) nor
+ * the beam tables fixed at construction (:116-156). */
+int f110_update_params(f110_handle *h, const double *params18_host, int32_t agent_idx);
 
 /* Optional: replace the library's libm-computed tables by the caller's
  * (numpy-computed, as in the reference).  sines/cosines: [theta_dis]

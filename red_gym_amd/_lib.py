@@ -41,7 +41,7 @@ SYMBOLS = {
     'f110_create': [C.POINTER(Config), C.POINTER(_VP)],
     'f110_destroy': [_VP],
     'f110_last_error': [],
-    'f110_update_params': [_VP, _VP],
+    'f110_update_params': [_VP, _VP, _I32],
     'f110_set_tables': [_VP, _VP, _VP, _VP, _VP, _VP],
     'f110_set_map_occupancy': [_VP, _VP, _I32, _I32, _D, _D, _D, _D, _D],
     'f110_set_map_dt': [_VP, _VP, _I32, _I32, _D, _D, _D, _D, _D],

@@ -60,15 +60,19 @@ class Simulator(object):
                                    num_agents=self.num_agents, timestep=self.time_step, ego_idx=self.ego_idx,
                                    integrator=self.integrator, fov=self.fov, seed=self.seed, autoreset=False,
                                    keep_f64_scans=True)
+            for prm, idx in getattr(self, '_pending_params', []):
+                self._vec.update_params(prm, idx)
+            self._pending_params = []
         else:
             self._vec.update_map(map_path, map_ext)
 
     def update_params(self, params, agent_idx=-1):
         if agent_idx >= self.num_agents:
             raise IndexError('Index given is out of bounds for list of agents.')
-        self.params = params
         if self._vec is not None:
-            self._vec.update_params(params)
+            self._vec.update_params(params, agent_idx)
+        else:
+            self._pending_params = getattr(self, '_pending_params', []) + [(params, agent_idx)]
 
     def _need_map(self):
         if self._vec is None:

@@ -38,7 +38,9 @@ static int fail(int code, const char *fmt, ...)
 
 struct f110_handle {
     f110_config cfg;
-    Params params;
+    Params params;                    // Simulator.params: the constructor's (GJK vertices, base_classes.py:542)
+    Params agent_params[F110_MAX_AGENTS]; // RaceCar.params per agent index
+    Params *d_agent_params = nullptr;
     bool has_map = false, bound = false;
     f110_buffers bufs;
     // device tables owned by the handle
@@ -205,6 +207,8 @@ static int upload_beam_cs(f110_handle *h, const double *scan_angles)
     return F110_OK;
 }
 
+static int upload_agent_params(f110_handle *h);
+
 // (Re)builds the interleaved {cos, sin} device table from the host copies.
 static int upload_cs(f110_handle *h)
 {
@@ -243,6 +247,7 @@ extern "C" int f110_create(const f110_config *cfg, f110_handle **out)
     if (!h) return fail(F110_E_INVALID, "f110_create: out of host memory");
     h->cfg = *cfg;
     memcpy(h->params.v, cfg->params, sizeof(double) * P_COUNT);
+    for (int i = 0; i < F110_MAX_AGENTS; i++) h->agent_params[i] = h->params;
     memset(&h->bufs, 0, sizeof(h->bufs));
     memset(&h->map, 0, sizeof(h->map));
     // laser_models.py:367-368
@@ -257,7 +262,7 @@ extern "C" int f110_create(const f110_config *cfg, f110_handle **out)
     if ((rc = upload_cs(h)) || (rc = upload(&h->d_zero_row, zeros.data(), zeros.size())) ||
         (rc = upload(&h->d_scan_angles, ang.data(), ang.size())) || (rc = upload_beam_cs(h, ang.data())) ||
         (rc = upload(&h->d_beam_cosines, bcos.data(), bcos.size())) ||
-        (rc = upload(&h->d_side, side.data(), side.size())) || (rc = set_beam_order(h))) {
+        (rc = upload(&h->d_side, side.data(), side.size())) || (rc = set_beam_order(h)) || (rc = upload_agent_params(h))) {
         f110_destroy(h);
         return rc;
     }
@@ -270,19 +275,30 @@ extern "C" void f110_destroy(f110_handle *h)
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
     void *ptrs[] = {h->d_cs, h->d_beam_cs, h->d_zero_row, h->d_scan_angles, h->d_beam_cosines, h->d_side,
-                    h->d_cells, h->d_lut, h->d_dt, h->d_noise, h->d_chunk0};
+                    h->d_cells, h->d_lut, h->d_dt, h->d_noise, h->d_chunk0, h->d_agent_params};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
     delete h;
 }
 
-extern "C" int f110_update_params(f110_handle *h, const double *p)
+static int upload_agent_params(f110_handle *h)
+{
+    if (!h->d_agent_params) HIP_TRY(hipMalloc((void **)&h->d_agent_params, sizeof(Params) * F110_MAX_AGENTS));
+    // enqueued steps may still read the table
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(h->d_agent_params, h->agent_params, sizeof(Params) * F110_MAX_AGENTS, hipMemcpyHostToDevice));
+    return F110_OK;
+}
+
+extern "C" int f110_update_params(f110_handle *h, const double *p, int32_t agent_idx)
 {
     if (!h || !p) return fail(F110_E_INVALID, "f110_update_params: null argument");
-    memcpy(h->params.v, p, sizeof(double) * P_COUNT);
-    memcpy(h->cfg.params, p, sizeof(double) * P_COUNT);
-    return F110_OK;
+    if (agent_idx >= h->cfg.num_agents) return fail(F110_E_INDEX, "Index given is out of bounds for list of agents.");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    for (int i = 0; i < h->cfg.num_agents; i++)
+        if (agent_idx < 0 || agent_idx == i) memcpy(h->agent_params[i].v, p, sizeof(double) * P_COUNT);
+    return upload_agent_params(h);
 }
 
 extern "C" int f110_set_tables(f110_handle *h, const double *sines, const double *cosines, const double *ang,
@@ -478,7 +494,7 @@ static int run_step(f110_handle *h, const double *actions, int reset_only, hipSt
     DynArgs d;
     d.n_cars = N; d.agents = c.num_agents; d.state = b.state; d.steer_buf = b.steer_buf; d.steer_cnt = b.steer_cnt;
     d.noise_step = b.noise_step; d.actions = actions; d.spawn = b.spawn; d.pending_reset = b.pending_reset;
-    d.reset_only = reset_only; d.pose_snap = b.pose_snap; d.in_collision = b.in_collision; d.params = h->params; d.time_step = c.timestep;
+    d.reset_only = reset_only; d.pose_snap = b.pose_snap; d.in_collision = b.in_collision; d.agent_params = h->d_agent_params; d.time_step = c.timestep;
     d.integrator = c.integrator;
     hipLaunchKernelGGL(dynamics_kernel, dim3((N + 255) / 256), dim3(256), 0, st, d);
     HIP_TRY(hipGetLastError());
@@ -501,7 +517,7 @@ static int run_step(f110_handle *h, const double *actions, int reset_only, hipSt
     if (c.num_agents > 1) {
         OppArgs o;
         o.n_cars = N; o.agents = c.num_agents; o.nb = c.num_beams; o.state = b.state; o.pose_snap = b.pose_snap;
-        o.in_collision = b.in_collision; o.scan_angles = h->d_scan_angles; o.beam_cs = h->d_beam_cs; o.car_length = h->params.v[P_LENGTH]; o.car_width = h->params.v[P_WIDTH];
+        o.in_collision = b.in_collision; o.scan_angles = h->d_scan_angles; o.beam_cs = h->d_beam_cs; o.agent_params = h->d_agent_params;
         o.pending_reset = b.pending_reset; o.reset_only = reset_only; o.scans32 = b.scans; o.scans64 = b.scans_f64;
         hipLaunchKernelGGL(opponents_kernel, dim3((N + 3) / 4), dim3(256), 0, st, o);
         HIP_TRY(hipGetLastError());
@@ -642,7 +658,7 @@ extern "C" int f110_update_pose(f110_handle *h, double *state, double *steer_buf
     DynArgs d;
     memset(&d, 0, sizeof(d));
     d.n_cars = n; d.agents = 1; d.state = state; d.steer_buf = steer_buf; d.steer_cnt = steer_cnt; d.actions = actions;
-    d.params = h->params; d.time_step = h->cfg.timestep; d.integrator = h->cfg.integrator;
+    d.agent_params = h->d_agent_params; d.time_step = h->cfg.timestep; d.integrator = h->cfg.integrator;
     hipLaunchKernelGGL(dynamics_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, d);
     HIP_TRY(hipGetLastError());
     return F110_OK;

@@ -364,7 +364,7 @@ struct OppArgs {
     const uint8_t *in_collision; // [N]
     const double *scan_angles;
     const double2 *beam_cs;   // [nb] {cos, sin}(scan_angles)
-    double car_length, car_width;
+    const Params *agent_params; // [agents]: a car sizes its opponents with its OWN params (base_classes.py:221)
     const uint8_t *pending_reset;
     int reset_only;
     float *scans32;           // [N,nb] or NULL
@@ -388,7 +388,8 @@ __global__ __launch_bounds__(256, F110_OPP_MIN_WAVES) void opponents_kernel(OppA
         if (a0 + j == car) continue;
         const double *op = a.pose_snap + (size_t)(a0 + j) * 3;
         double verts[4][2];
-        get_vertices(op[0], op[1], op[2], a.car_length, a.car_width, verts);
+        const Params &P = a.agent_params[car - a0];
+        get_vertices(op[0], op[1], op[2], P.v[P_LENGTH], P.v[P_WIDTH], verts);
         ray_cast_wave(px, py, pyaw, verts, a.scan_angles, a.beam_cs, a.nb, lane,
                       a.scans64 ? a.scans64 + (size_t)car * a.nb : nullptr,
                       a.scans32 ? a.scans32 + (size_t)car * a.nb : nullptr, nullptr);
@@ -408,7 +409,7 @@ struct DynArgs {
     int reset_only;
     double *pose_snap;    // [N,3] or NULL
     uint8_t *in_collision;// [N] or NULL: cleared here, set by scan_kernel
-    Params params;
+    const Params *agent_params; // [agents] device: RaceCar.params of agent i (base_classes.py:84,169)
     double time_step;
     int integrator;
 };
@@ -445,7 +446,8 @@ __global__ __launch_bounds__(256) void dynamics_kernel(DynArgs a)
         steer = a.actions[(size_t)car * 2];
         speed = a.actions[(size_t)car * 2 + 1];
     }
-    update_pose(st, sb, sc, steer, speed, a.params, a.time_step, a.integrator);
+    const Params P = a.agent_params[car % a.agents];
+    update_pose(st, sb, sc, steer, speed, P, a.time_step, a.integrator);
 #pragma unroll
     for (int i = 0; i < 7; i++) a.state[(size_t)car * 7 + i] = st[i];
     a.steer_buf[(size_t)car * 2] = sb[0];

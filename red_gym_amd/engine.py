@@ -193,10 +193,12 @@ class Engine(object):
         _lib.check(self.lib.f110_get_map_dt(self._h, _np_ptr(out)))
         return out
 
-    def update_params(self, params):
-        self.params = dict(params)
-        pv = params_vec(self.params)
-        _lib.check(self.lib.f110_update_params(self._h, _np_ptr(pv)))
+    def update_params(self, params, agent_idx=-1):
+        """base_classes.py:507-527: all agents (agent_idx < 0) or one agent of every env."""
+        pv = params_vec(params)
+        _lib.check(self.lib.f110_update_params(self._h, _np_ptr(pv), int(agent_idx)))
+        if agent_idx < 0:
+            self.params = dict(params)
 
     # ------------------------------------------------------------------ step path
     def reset(self, poses, mask=None):

@@ -96,11 +96,11 @@ class F110VecEnv(object):
         return self.eng.pure_pursuit(waypoints, lookahead, vgain, wheelbase)
 
     def update_params(self, params, index=-1):
-        """base_classes.py:507-527; all cars of a batch share one parameter set."""
-        if index >= self.num_agents:
-            raise IndexError('Index given is out of bounds for list of agents.')
-        self.params = dict(params)
-        self.eng.update_params(self.params)
+        """base_classes.py:507-527: index < 0 updates every agent, otherwise agent `index` of
+        every env; IndexError beyond the agent list."""
+        self.eng.update_params(params, index)
+        if index < 0:
+            self.params = dict(params)
 
     def update_map(self, map_path, map_ext):
         self.eng.set_map(map_path, map_ext)

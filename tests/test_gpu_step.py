@@ -188,3 +188,37 @@ def test_reset_errors(assets):
     with pytest.raises(IndexError):
         env.update_params(env.params, index=5)
     env.close()
+
+
+def test_per_agent_update_params(assets):
+    """Simulator.update_params(params, agent_idx) (base_classes.py:507-527): only that
+    agent's dynamics change; the oracle models it with a second env using the new params."""
+    from red_gym_amd import Integrator
+    B, A = 4, 2
+    rl = np.loadtxt(os.path.join(assets, 'example_waypoints.csv'), delimiter=';', skiprows=3)
+    poses = np.stack([[[rl[(97 * b) % 783, 1], rl[(97 * b) % 783, 2], rl[(97 * b) % 783, 3] + np.pi / 2],
+                       [rl[(97 * b + 300) % 783, 1], rl[(97 * b + 300) % 783, 2], rl[(97 * b + 300) % 783, 3] + np.pi / 2]]
+                      for b in range(B)])
+    heavy = dict(oracle.DEFAULT_PARAMS, m=5.0, I=0.08, mu=0.7)
+    env = _vec(assets, B, A, integrator=Integrator.RK4)
+    env.update_params(heavy, index=1)
+    with pytest.raises(IndexError):
+        env.update_params(heavy, index=2)
+    env.reset(poses)
+    # far-apart cars do not interact, so each agent can be checked against a 1-agent oracle env
+    o0 = [_mk_oracle_env(assets, 1, 64) for _ in range(B)]
+    sc = oracle.Scanner(1080, 2 * np.pi)
+    sc.set_map(os.path.join(assets, 'example_map.yaml'), '.png')
+    o1 = [oracle.Env(sc, 1, params=heavy, noise=oracle.noise_table(12345, 64)) for _ in range(B)]
+    for b in range(B):
+        o0[b].reset(poses[b, 0:1]); o1[b].reset(poses[b, 1:2])
+    rng = np.random.default_rng(5)
+    for k in range(40):
+        act = np.stack([rng.uniform(-0.3, 0.3, (B, A)), rng.uniform(2, 7, (B, A))], axis=2)
+        env.step(act)
+        st = _np(env.state)
+        for b in range(B):
+            assert np.allclose(st[b, 0], o0[b].step(act[b, 0:1])['state'][0], rtol=0, atol=1e-9), (k, b)
+            assert np.allclose(st[b, 1], o1[b].step(act[b, 1:2])['state'][0], rtol=0, atol=1e-9), (k, b)
+    assert not np.allclose(st[:, 0, 3], st[:, 1, 3])
+    env.close()
