@@ -41,6 +41,7 @@ struct f110_handle {
     Params params;                    // Simulator.params: the constructor's (GJK vertices, base_classes.py:542)
     Params agent_params[F110_MAX_AGENTS]; // RaceCar.params per agent index
     Params *d_agent_params = nullptr;
+    OppPair *d_opp_pairs = nullptr;   // [N, A-1] opponent ray-cast scratch
     bool has_map = false, bound = false;
     f110_buffers bufs;
     // device tables owned by the handle
@@ -209,6 +210,15 @@ static int upload_beam_cs(f110_handle *h, const double *scan_angles)
 
 static int upload_agent_params(f110_handle *h);
 
+// scratch of the opponent ray cast: allocated here, never in f110_step
+static int alloc_opp_pairs(f110_handle *h)
+{
+    if (h->cfg.num_agents < 2) return F110_OK;
+    const size_t n = (size_t)h->cfg.num_envs * h->cfg.num_agents * (h->cfg.num_agents - 1);
+    HIP_TRY(hipMalloc((void **)&h->d_opp_pairs, n * sizeof(OppPair)));
+    return F110_OK;
+}
+
 // (Re)builds the interleaved {cos, sin} device table from the host copies.
 static int upload_cs(f110_handle *h)
 {
@@ -262,7 +272,7 @@ extern "C" int f110_create(const f110_config *cfg, f110_handle **out)
     if ((rc = upload_cs(h)) || (rc = upload(&h->d_zero_row, zeros.data(), zeros.size())) ||
         (rc = upload(&h->d_scan_angles, ang.data(), ang.size())) || (rc = upload_beam_cs(h, ang.data())) ||
         (rc = upload(&h->d_beam_cosines, bcos.data(), bcos.size())) ||
-        (rc = upload(&h->d_side, side.data(), side.size())) || (rc = set_beam_order(h)) || (rc = upload_agent_params(h))) {
+        (rc = upload(&h->d_side, side.data(), side.size())) || (rc = set_beam_order(h)) || (rc = upload_agent_params(h)) || (rc = alloc_opp_pairs(h))) {
         f110_destroy(h);
         return rc;
     }
@@ -275,7 +285,7 @@ extern "C" void f110_destroy(f110_handle *h)
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
     void *ptrs[] = {h->d_cs, h->d_beam_cs, h->d_zero_row, h->d_scan_angles, h->d_beam_cosines, h->d_side,
-                    h->d_cells, h->d_lut, h->d_dt, h->d_noise, h->d_chunk0, h->d_agent_params};
+                    h->d_cells, h->d_lut, h->d_dt, h->d_noise, h->d_chunk0, h->d_agent_params, h->d_opp_pairs};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
@@ -519,7 +529,11 @@ static int run_step(f110_handle *h, const double *actions, int reset_only, hipSt
         o.n_cars = N; o.agents = c.num_agents; o.nb = c.num_beams; o.state = b.state; o.pose_snap = b.pose_snap;
         o.in_collision = b.in_collision; o.scan_angles = h->d_scan_angles; o.beam_cs = h->d_beam_cs; o.agent_params = h->d_agent_params;
         o.pending_reset = b.pending_reset; o.reset_only = reset_only; o.scans32 = b.scans; o.scans64 = b.scans_f64;
-        hipLaunchKernelGGL(opponents_kernel, dim3((N + 3) / 4), dim3(256), 0, st, o);
+        o.pairs = h->d_opp_pairs;
+        const int npairs = N * (c.num_agents - 1), wpcar = (c.num_beams + 63) / 64;
+        hipLaunchKernelGGL(opp_setup_kernel, dim3((npairs + 127) / 128), dim3(128), 0, st, o);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(opp_apply_kernel, dim3((N * wpcar + 3) / 4), dim3(256), 0, st, o);
         HIP_TRY(hipGetLastError());
     }
 
