@@ -222,3 +222,36 @@ def test_per_agent_update_params(assets):
             assert np.allclose(st[b, 1], o1[b].step(act[b, 1:2])['state'][0], rtol=0, atol=1e-9), (k, b)
     assert not np.allclose(st[:, 0, 3], st[:, 1, 3])
     env.close()
+
+
+def test_noise_table_grows_before_it_is_exhausted(assets):
+    """A car that keeps driving past the device noise table: the host doubles the table
+    (same NumPy stream continued) before any car can wrap (engine._grow_noise_if_needed)."""
+    from red_gym_amd.engine import Engine
+    import torch
+    e = Engine(num_envs=2, num_agents=1, noise_steps=4, keep_f64_scans=True)
+    e.set_map(os.path.join(assets, 'example_map.yaml'), '.png')
+    poses = np.array([[[0.7, 0.0, 1.37079632679]], [[0.7, 0.0, 1.37079632679]]])
+    e.reset(torch.as_tensor(poses))
+    orc = _mk_oracle_env(assets, 1, 64)
+    oo = orc.reset(poses[0])
+    act = np.zeros((2, 1, 2))
+    act[:, 0, 1] = 1.0
+    for k in range(30):
+        e.step(torch.as_tensor(act))
+        oo = orc.step(act[0])
+        assert np.allclose(_np(e.t['scans_f64'])[0, 0], oo['scans'][0], rtol=0, atol=1e-9), k
+    assert e._noise_dev_rows >= 32 and int(e.t['noise_step'].max()) == 31
+    e.close()
+
+
+def test_update_map_switches_tables(assets, golden):
+    env = _vec(assets, 1, 1, noise_std=0)
+    g = golden('g1_scan.npz')
+    assert np.array_equal(_np(env.eng.scan(g['ex_poses'][:3])), g['ex_scans'][:3])
+    env.update_map(os.path.join(assets, 'maps', 'berlin.yaml'), '.png')
+    e47 = _np(env.eng.scan(g['berlin_poses'][:2]))  # fov 2pi here, so only compare with the oracle
+    s = oracle.Scanner(1080, 2 * np.pi)
+    s.set_map(os.path.join(assets, 'maps', 'berlin.yaml'), '.png')
+    assert np.array_equal(e47, s.scan_batch(g['berlin_poses'][:2]))
+    env.close()

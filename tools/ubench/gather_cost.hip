@@ -20,7 +20,13 @@ __global__ void gather(const uint16_t *tab, unsigned tab_bytes, int pattern, int
     case 5: off = (lane >> 3) * 128 + (lane & 7) * 2; break;  // 8 lines, 8 lanes each
     case 6: off = (lane & 7) * 128 + (lane >> 3) * 2; break;  // 8 lines, strided lanes
     case 7: off = (lane >> 4) * 128 + (lane & 15) * 2; break; // 4 lines
-    default: off = 0xffffffffu; break;                        // 8: out of range (no access)
+    case 8: off = 0xffffffffu; break;                         // out of range (no access)
+    case 9: off = ((lane * 37u) & 63u) * 2; break;            // one 128-B line, scattered 2-B positions
+    case 10: off = ((lane * 37u) & 31u) * 2; break;           // one 64-B half line, scattered
+    case 11: off = ((lane * 37u) & 15u) * 2; break;           // one 32-B sector, scattered
+    case 12: off = (lane >> 4) * 128 + ((lane * 37u) & 63u) * 2; break; // one line per 16-lane group, scattered inside
+    case 13: off = (lane >> 4) * 128 + ((lane * 5u) & 15u) * 8; break;  // one line per group, 8-B apart positions
+    default: off = (lane >> 4) * 128 + (lane & 1) * 64 + ((lane >> 1) & 7) * 2; break; // 14: two 64-B halves per group
     }
     unsigned acc = 0;
     for (int i = 0; i < iters; i++) {
@@ -47,8 +53,10 @@ int main()
     hipEventCreate(&e0);
     hipEventCreate(&e1);
     const char *names[] = {"1 address", "1 line contiguous", "16 lines, quad-aligned", "64 lines", "16 lines, quad-scattered",
-                           "8 lines x 8 lanes", "8 lines strided lanes", "4 lines x 16 lanes", "out of range"};
-    for (int pat = 0; pat <= 8; pat++) {
+                           "8 lines x 8 lanes", "8 lines strided lanes", "4 lines x 16 lanes", "out of range",
+                           "1 line scattered", "1 half-line scattered", "1 sector scattered", "line/group scattered",
+                           "line/group 8B apart", "2 halves per group"};
+    for (int pat = 0; pat <= 14; pat++) {
         hipLaunchKernelGGL(gather, dim3(cus * wps), dim3(256), 0, 0, tab, tab_bytes, pat, 50, out);
         hipDeviceSynchronize();
         hipEventRecord(e0);
