@@ -56,7 +56,7 @@ struct f110_handle {
     double *d_noise = nullptr;
     long long noise_T = 0;
     MapDev map;
-    bool ident = false, pow2 = false, freeze = true;
+    bool ident = false, pow2 = false;
     double theta_inc = 0;
     // measurement aid (f110_profile_begin/end)
     std::vector<hipEvent_t> prof_ev; // pairs: [2*i] before, [2*i+1] after the scan launch
@@ -337,7 +337,6 @@ static int install_map(f110_handle *h, const double *dt, const uint32_t *d2_or_n
     const int strips = (W + 2 + 7) >> 3, Hp = ((H + 2 + 7) >> 3) << 3;
     const size_t n_tiled = (size_t)strips * Hp * 8;
     std::vector<uint16_t> cells(n_tiled, (uint16_t)CODE_BORDER);
-    double min_pos = INFINITY;
     for (size_t i = 0; i < n; i++) {
         uint64_t d2;
         if (d2_or_null) d2 = d2_or_null[i];
@@ -347,7 +346,6 @@ static int install_map(f110_handle *h, const double *dt, const uint32_t *d2_or_n
             d2 = (r >= 0 && r < 4.0e18) ? (uint64_t)r : (uint64_t)CODE_ESC;
             if (d2 < (uint64_t)CODE_ESC && res * std::sqrt((double)d2) != dt[i]) d2 = CODE_ESC;
         }
-        if (dt[i] > 0 && dt[i] < min_pos) min_pos = dt[i];
         const size_t r = i / W + 1, c = i % W + 1;
         const size_t t = ((c >> 3) * (size_t)Hp + r) * 8 + (c & 7);
         uint16_t code;
@@ -356,8 +354,6 @@ static int install_map(f110_handle *h, const double *dt, const uint32_t *d2_or_n
         else code = (uint16_t)CODE_ESC;
         cells[t] = code;
     }
-    // a finished ray may idle unattended only if every table value is 0 or > eps
-    h->freeze = !(min_pos > h->cfg.eps);
     std::vector<double> lut(CODE_ESC);
     for (int i = 0; i < CODE_ESC; i++) lut[i] = res * std::sqrt((double)i);
     HIP_TRY(hipSetDevice(h->cfg.device));
@@ -461,14 +457,14 @@ static ScanDev scan_dev(const f110_handle *h)
     return s;
 }
 
-template <bool STEP, bool FREEZE>
+template <bool STEP>
 static int launch_scan_t(f110_handle *h, const ScanArgs &a, hipStream_t st)
 {
     const dim3 grid((a.n_cars * a.wpc + SCAN_WAVES - 1) / SCAN_WAVES), block(SCAN_THREADS);
-    if (h->ident && h->pow2) hipLaunchKernelGGL((scan_kernel<true, true, STEP, FREEZE>), grid, block, 0, st, a);
-    else if (h->ident) hipLaunchKernelGGL((scan_kernel<true, false, STEP, FREEZE>), grid, block, 0, st, a);
-    else if (h->pow2) hipLaunchKernelGGL((scan_kernel<false, true, STEP, FREEZE>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((scan_kernel<false, false, STEP, FREEZE>), grid, block, 0, st, a);
+    if (h->ident && h->pow2) hipLaunchKernelGGL((scan_kernel<true, true, STEP>), grid, block, 0, st, a);
+    else if (h->ident) hipLaunchKernelGGL((scan_kernel<true, false, STEP>), grid, block, 0, st, a);
+    else if (h->pow2) hipLaunchKernelGGL((scan_kernel<false, true, STEP>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((scan_kernel<false, false, STEP>), grid, block, 0, st, a);
     HIP_TRY(hipGetLastError());
     return F110_OK;
 }
@@ -492,8 +488,7 @@ static int launch_scan(f110_handle *h, const ScanArgs &a_in, hipStream_t st)
 {
     ScanArgs a = a_in;
     a.wpc = waves_per_car(a.n_cars, a.scan.nb);
-    if (h->freeze) return a.state ? launch_scan_t<true, true>(h, a, st) : launch_scan_t<false, true>(h, a, st);
-    return a.state ? launch_scan_t<true, false>(h, a, st) : launch_scan_t<false, false>(h, a, st);
+    return a.state ? launch_scan_t<true>(h, a, st) : launch_scan_t<false>(h, a, st);
 }
 
 static int run_step(f110_handle *h, const double *actions, int reset_only, hipStream_t st)

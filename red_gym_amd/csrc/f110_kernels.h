@@ -116,11 +116,10 @@ __device__ inline double dist_lookup(const MapView &m, const double *lds_lut, do
     const int cc = med3_i32(ci, -1, m.W) + 1;  // padded column 0..W+1
     const int rr = med3_i32(ri, -1, m.H);      // padded row - 1 (the +1 is the +16 below)
     unsigned off = __umul24((unsigned)cc >> 3, m.strip_bytes) + (((unsigned)rr << 4) + 16u) + (((unsigned)cc & 7u) << 1);
-#ifndef F110_PARKED_LOAD
     // a finished ray presents an out-of-range offset: the hardware range check answers 0
-    // (= d2 0 = distance 0.0, which parks the ray) without occupying the L1 tag pipeline
+    // (= d2 0 = distance 0.0, which parks the ray: total += 0, x += 0*c) without occupying
+    // the L1 tag pipeline
     off = live ? off : 0xffffffffu;
-#endif
     // buffer load: 32-bit per-lane offset against a scalar descriptor
     const unsigned code = (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(m.cells_rsrc, (int)off, 0, 0);
     // common case: one ds_read_b64 (d2 < 1023: within ~2 m of a wall; or the border slot)
@@ -188,17 +187,14 @@ struct ScanArgs {
     uint32_t *lookups;           // [N] or NULL (accumulated)
 };
 
-// One wavefront per car.  Lanes own rays; a finished ray idles (see FREEZE) until at least REFILL_MIN_IDLE lanes are idle, then every idle
+// One wavefront per car.  Lanes own rays; a finished ray idles (its lookups return 0.0) until at least REFILL_MIN_IDLE lanes are idle, then every idle
 // lane (a) finishes its previous beam -- noise, iTTC candidate test, fp32/fp64 store --
 // and (b) takes the next beam of the car.  No LDS staging of the scan: the only LDS
 // use is the 8 KiB distance LUT shared by the workgroup, so occupancy is register-bound.
 // STEP: full env step (noise + iTTC + state update); false: ScanSimulator2D.scan(pose, None).
 constexpr int MAX_CHUNKS = 64; // beams are handed out in chunks of 64 (num_beams <= 4096)
 
-// FREEZE: the table holds values in (0, eps] (or none equal to 0), so a finished ray
-// cannot be left to its own devices; otherwise a ray that stopped on d == 0 stays put by
-// itself and one that ran past max_range keeps growing and is clamped when it is emitted.
-template <bool IDENT, bool POW2, bool STEP, bool FREEZE>
+template <bool IDENT, bool POW2, bool STEP>
 #ifndef F110_SCAN_MIN_WAVES
 #define F110_SCAN_MIN_WAVES 8
 #endif
@@ -329,12 +325,7 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
 #elif F110_COUNT_MODE == 3   // diagnostics: wave iterations of the drain phase
                 nlook += go == 0 ? 1 : 0;
 #endif
-#ifndef F110_PARKED_LOAD
                 const double d = dist_lookup<IDENT, POW2>(mv, s_lut, x, y, active);
-#else
-                double d = dist_lookup<IDENT, POW2>(mv, s_lut, x, y, active);
-                if (FREEZE) d = active ? d : 0.0; // park finished rays explicitly
-#endif
                 total += d;
                 x += d * c;
                 y += d * s;
