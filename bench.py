@@ -151,6 +151,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=50)
     ap.add_argument('--envs', type=int, default=65536, help='envs per GPU')
     ap.add_argument('--agents', type=int, default=1)
+    ap.add_argument('--policy', choices=['random', 'pure_pursuit'], default='random',
+                    help='random actions (the headline workload, SURVEY 8d) or closed-loop pure pursuit on the GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-scan-events', action='store_true',
                     help='do not bracket the scan kernel with hipEvents (roofline becomes null)')
@@ -183,7 +185,17 @@ def main():
     lookups.zero_()
     if not args.no_scan_events:
         env.eng.profile_begin(K)
-    elapsed = timed_steps(ranks, lambda k: env.step(acts[(W + k) % POOL]), K)
+    if args.policy == 'pure_pursuit':
+        # secondary mode: the reference's waypoint follower runs on the GPU in front of every step
+        rl = workload.load_waypoints(workload.RACELINE)
+        wp = torch.as_tensor(np.ascontiguousarray(rl[:, [1, 2, 5]]), device=dev)
+        step_fn = lambda k: env.step(env.pure_pursuit(wp, 0.82461887897713965, 1.375))  # noqa: E731
+        for k in range(W):
+            step_fn(k)
+        lookups.zero_()
+    else:
+        step_fn = lambda k: env.step(acts[(W + k) % POOL])  # noqa: E731
+    elapsed = timed_steps(ranks, step_fn, K)
 
     out = None
     if rank == 0:
@@ -216,8 +228,9 @@ def main():
                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
                'data': 'synthetic',
                'config': {'workload': '%d envs x %d agent(s) per GPU, example_map, 1080 beams, RK4 single-track, '
-                                      'noise+iTTC%s, lap logic, autoreset; random actions'
-                                      % (B, A, '+GJK+opponent ray-cast' if A > 1 else ''),
+                                      'noise+iTTC%s, lap logic, autoreset; %s'
+                                      % (B, A, '+GJK+opponent ray-cast' if A > 1 else '',
+                                         'random actions' if args.policy == 'random' else 'GPU pure-pursuit policy in the loop'),
                           'envs_per_gpu': B, 'agents': A, 'num_beams': 1080, 'map': 'example_map',
                           'sharding': 'independent env shards, no collective on the step path'},
                'roofline': roof}

@@ -296,7 +296,9 @@ class Engine(object):
         n = st.numel() // 7
         if out is None:
             out = torch.empty((n, 2), dtype=torch.float64, device=self.device)
-        waypoints = self._dev64(waypoints, (-1, 3))
+        if not (torch.is_tensor(waypoints) and waypoints.device == self.device and waypoints.dtype == torch.float64
+                and waypoints.is_contiguous()):
+            waypoints = self._dev64(waypoints, (-1, 3))
         _lib.check(self.lib.f110_pure_pursuit(self._h, _ptr(waypoints), waypoints.shape[0], float(lookahead),
                                               float(vgain), float(wheelbase), float(max_reacquire), _ptr(st), n,
                                               _ptr(out), self._stream()))

@@ -88,6 +88,36 @@ class F110VecEnv(object):
         self.eng.step(self._as_dev(actions, 2))
         return self._result()
 
+    # ------------------------------------------------------------------ hipGraph replay
+    def capture_step(self, policy=None):
+        """Captures one step (optionally preceded by a device-side policy that fills the
+        action buffer, e.g. `lambda env, out: env.eng.pure_pursuit(wp, tlad, vgain, out=out)`)
+        into a HIP graph.  f110_step neither allocates nor synchronises, so the three or four
+        kernel launches replay from one graph launch; `step_graph()` then costs one host call.
+        Returns the static action buffer [B,A,2] to write into when no policy is given."""
+        self._g_actions = torch.zeros((self.num_envs, self.num_agents, 2), dtype=torch.float64, device=self.device)
+        self.eng._grow_noise_if_needed()
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(self._graph, stream=side):
+                if policy is not None:
+                    policy(self, self._g_actions.view(-1, 2))
+                self.eng.step(self._g_actions)
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        # the capture itself did not execute anything; undo its host-side step accounting
+        self.eng.host_steps_bound -= 1
+        return self._g_actions
+
+    def step_graph(self, actions=None):
+        if actions is not None:
+            self._g_actions.copy_(self._as_dev(actions, 2))
+        self.eng._grow_noise_if_needed()
+        self._graph.replay()
+        self.eng.host_steps_bound += 1
+        return self._result()
+
     def pure_pursuit(self, waypoints, lookahead, vgain, wheelbase=0.17145 + 0.15875):
         """Batched pure-pursuit actions for the current poses (examples/waypoint_follow.py planner
         on the GPU); waypoints [M,3] = (x, y, speed)."""

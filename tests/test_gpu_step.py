@@ -255,3 +255,26 @@ def test_update_map_switches_tables(assets, golden):
     s.set_map(os.path.join(assets, 'maps', 'berlin.yaml'), '.png')
     assert np.array_equal(e47, s.scan_batch(g['berlin_poses'][:2]))
     env.close()
+
+
+def test_hipgraph_replay_equals_eager(assets):
+    """f110_step is capture-safe (no allocation, no synchronisation): a HIP graph of
+    planner + step replays to the same bits as eager launches."""
+    import torch
+    from red_gym_amd import workload
+    B = 256
+    rl = np.loadtxt(os.path.join(assets, 'example_waypoints.csv'), delimiter=';', skiprows=3)
+    wp = torch.as_tensor(np.ascontiguousarray(rl[:, [1, 2, 5]]), device='cuda')
+    poses = workload.spawn_poses(B, 1)
+    tlad, vgain = 0.82461887897713965, 1.375
+    e1, e2 = _vec(assets, B, 1, autoreset=True), _vec(assets, B, 1, autoreset=True)
+    e1.reset(poses); e2.reset(poses)
+    e2.capture_step(policy=lambda env, out: env.eng.pure_pursuit(wp, tlad, vgain, out=out))
+    for k in range(50):
+        e1.step(e1.pure_pursuit(wp, tlad, vgain))
+        e2.step_graph()
+    torch.cuda.synchronize()
+    assert torch.equal(e1.state, e2.state) and torch.equal(e1.eng.t['scans'], e2.eng.t['scans'])
+    assert torch.equal(e1.eng.t['noise_step'], e2.eng.t['noise_step']) and int(e1.eng.t['noise_step'].max()) > 1
+    assert float(e2.state[:, 0, 3].mean()) > 3.0  # the fleet is racing
+    e1.close(); e2.close()
