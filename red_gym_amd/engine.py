@@ -36,6 +36,13 @@ def beam_tables(num_beams, fov, params):
     side_distances = np.zeros((num_beams,))
     dist_sides = params['width'] / 2.
     dist_fr = (params['lf'] + params['lr']) / 2.
+    # a beam at exactly 0 rad divides by sin(0) like the reference does (inf loses the min());
+    # only the RuntimeWarning is silenced
+    with np.errstate(divide='ignore'):
+        return _beam_tables_loop(num_beams, fov, scan_ang_incr, dist_sides, dist_fr, scan_angles, cosines, side_distances)
+
+
+def _beam_tables_loop(num_beams, fov, scan_ang_incr, dist_sides, dist_fr, scan_angles, cosines, side_distances):
     for i in range(num_beams):
         angle = -fov / 2. + i * scan_ang_incr
         scan_angles[i] = angle

@@ -278,3 +278,50 @@ def test_hipgraph_replay_equals_eager(assets):
     assert torch.equal(e1.eng.t['noise_step'], e2.eng.t['noise_step']) and int(e1.eng.t['noise_step'].max()) > 1
     assert float(e2.state[:, 0, 3].mean()) > 3.0  # the fleet is racing
     e1.close(); e2.close()
+
+
+@pytest.mark.parametrize('cfg', [
+    dict(map='maps/berlin', fov=4.7, num_beams=1080, A=2, ego_idx=1, integ='RK4'),      # res 0.05: guarded-reciprocal index path
+    dict(map='maps/skirk', fov=2 * np.pi, num_beams=271, A=1, ego_idx=0, integ='Euler'),  # odd beam count (partial chunk)
+    dict(map='example_map', fov=3.0, num_beams=64, A=3, ego_idx=2, integ='RK4'),          # one chunk, three agents
+])
+def test_step_path_odd_configs_vs_oracle(assets, cfg):
+    """Whole step path (dynamics, scan+noise+iTTC, opponents, GJK, lap logic) on other maps /
+    fov / beam counts / ego index, every env against an independent oracle env."""
+    from red_gym_amd import F110VecEnv, Integrator
+    B, A, T = 6, cfg['A'], 40
+    nb = cfg['num_beams']
+    map_base = os.path.join(assets, cfg['map'])
+    sc = oracle.Scanner(nb, cfg['fov'])
+    sc.set_map(map_base + '.yaml', '.png')
+    m = sc.map
+    rng = np.random.default_rng(77)
+    # free-space spawn cells with some clearance
+    free = np.argwhere(m['dt'] > 0.6)
+    pick = free[rng.choice(len(free), size=B * A, replace=False)]
+    poses = np.zeros((B, A, 3))
+    poses[..., 0] = (m['orig_x'] + (pick[:, 1] + 0.5) * m['resolution']).reshape(B, A)
+    poses[..., 1] = (m['orig_y'] + (pick[:, 0] + 0.5) * m['resolution']).reshape(B, A)
+    poses[..., 2] = rng.uniform(0, 6.28, (B, A))
+    poses[0, 1:, :2] = poses[0, 0, :2] + 0.2  # overlapping cars: GJK + opponent ray cast at close range
+    env = F110VecEnv(B, map=map_base, map_ext='.png', num_agents=A, fov=cfg['fov'], num_beams=nb,
+                     ego_idx=cfg['ego_idx'], integrator=getattr(Integrator, cfg['integ']), autoreset=False,
+                     keep_f64_scans=True)
+    noise = oracle.noise_table(12345, T + 2, num_beams=nb)
+    ors = [oracle.Env(sc, A, noise=noise, ego_idx=cfg['ego_idx'],
+                      integrator=oracle.RK4 if cfg['integ'] == 'RK4' else oracle.EULER) for _ in range(B)]
+    env.reset(poses)
+    oo = [ors[b].reset(poses[b]) for b in range(B)]
+    for k in range(T):
+        act = np.stack([rng.uniform(-0.4, 0.4, (B, A)), rng.uniform(0, 6, (B, A))], axis=2)
+        obs, _, done, info = env.step(act)
+        oo = [ors[b].step(act[b]) for b in range(B)]
+        st = _np(env.state)
+        for b in range(B):
+            assert np.allclose(st[b], oo[b]['state'], rtol=0, atol=1e-9), (k, b)
+            assert np.allclose(_np(obs['scans_f64'])[b], oo[b]['scans'], rtol=0, atol=1e-9), (k, b)
+            assert np.array_equal(_np(obs['collisions'])[b].astype(np.float64), oo[b]['collisions']), (k, b)
+            assert np.array_equal(_np(info['collision_idx'])[b].astype(np.float64), oo[b]['collision_idx']), (k, b)
+            assert bool(_np(done)[b]) == oo[b]['done'], (k, b)
+            assert np.array_equal(_np(info['toggles'])[b].astype(np.float64), oo[b]['toggles']), (k, b)
+    env.close()
