@@ -1,7 +1,9 @@
-// f110_kernels.h -- the three kernels of one batched env step on gfx950:
-//   dynamics_kernel  (lane per car)   RaceCar.update_pose minus the scan
-//   scan_kernel      (wave per car)   ScanSimulator2D.scan + noise + iTTC + opponent ray cast
-//   env_kernel       (lane per env)   GJK, collision flags, lap timing, done, autoreset
+// f110_kernels.h -- the kernels of one batched env step on gfx950, in launch order:
+//   dynamics_kernel   (lane per car)        RaceCar.update_pose minus the scan (+ reset)
+//   scan_kernel       (wave per car)        ScanSimulator2D.scan + noise + iTTC
+//   opp_setup_kernel  (lane per car pair)   \ RaceCar.ray_cast_agents, only when A > 1
+//   opp_apply_kernel  (lane per car, beam)  /
+//   env_kernel        (lane per env)        GJK, collision flags, iTTC state update, lap timing, done, autoreset
 // plus small function-level kernels used by the parity entry points.
 #pragma once
 #include "f110_device.h"
