@@ -52,7 +52,7 @@ struct f110_handle {
     double2 *d_beam_cs = nullptr;     // {cos, sin}(scan_angles) for the opponent ray cast
     double *d_zero_row = nullptr;     // noise row used when noise is off
     std::vector<double> h_sines, h_cosines;
-    double *d_lut = nullptr, *d_dt = nullptr;
+    double *d_lut = nullptr, *d_lut_lds = nullptr, *d_dt = nullptr;
     double *d_noise = nullptr;
     long long noise_T = 0;
     MapDev map;
@@ -285,7 +285,7 @@ extern "C" void f110_destroy(f110_handle *h)
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
     void *ptrs[] = {h->d_cs, h->d_beam_cs, h->d_zero_row, h->d_scan_angles, h->d_beam_cosines, h->d_side,
-                    h->d_cells, h->d_lut, h->d_dt, h->d_noise, h->d_chunk0, h->d_agent_params, h->d_opp_pairs};
+                    h->d_cells, h->d_lut, h->d_lut_lds, h->d_dt, h->d_noise, h->d_chunk0, h->d_agent_params, h->d_opp_pairs};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
@@ -366,8 +366,11 @@ static int install_map(f110_handle *h, const double *dt, const uint32_t *d2_or_n
     HIP_TRY(hipMemcpy(h->d_dt, dt, n * sizeof(double), hipMemcpyHostToDevice));
     int rc = upload(&h->d_lut, lut.data(), lut.size());
     if (rc) return rc;
+    std::vector<double> lut_lds(lut.begin(), lut.begin() + LUT_LDS);
+    lut_lds[CODE_BORDER] = dt[n - 1]; // dt[-1, -1]
+    if ((rc = upload(&h->d_lut_lds, lut_lds.data(), lut_lds.size()))) return rc;
     MapDev &m = h->map;
-    m.cells = h->d_cells; m.lut = h->d_lut; m.dt = h->d_dt;
+    m.cells = h->d_cells; m.lut = h->d_lut; m.lut_lds = h->d_lut_lds; m.dt = h->d_dt;
     m.H = H; m.W = W; m.strip_bytes = (unsigned)Hp * 16u; m.cells_bytes = (unsigned)(n_tiled * sizeof(uint16_t)); m.res = res; m.rinv = 1.0 / res;
     m.ox = ox; m.oy = oy; m.oc = oc; m.os = os;
     m.wres = W * res; // width * resolution (laser_models.py:79)

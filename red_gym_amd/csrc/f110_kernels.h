@@ -59,6 +59,7 @@ struct MapDev {
     unsigned cells_bytes;
     unsigned strip_bytes;   // Hp * 16, Hp = H + 2 rounded up to a multiple of 8
     const double *lut;      // [65534] resolution*sqrt(d2), indexed by d2
+    const double *lut_lds;  // [LUT_LDS] image staged in LDS: lut[0..CODE_BORDER-1], then dt[-1,-1]
     const double *dt;       // [H*W] exact fp64 distance table (escape path, rarely touched)
     int H, W;
     double res, rinv, ox, oy, oc, os, wres, hres, oob; // oob = dt[H-1][W-1]
@@ -136,6 +137,19 @@ __device__ inline double dist_lookup(const MapView &m, const double *lds_lut, do
     return d;
 }
 
+// np.fmod(t, td) (laser_models.py:170) without the generic library loop: for |t/td| < 2^31
+// the result t - trunc(t/td)*td is exact (fmod results are representable and q*td is an
+// exact product); the rounded quotient can only be one too large in magnitude, which
+// shows as a remainder of the wrong sign and is redone with the corrected quotient.
+__device__ inline double fmod_small(double t, double td)
+{
+    const double qf = trunc(t / td);
+    if (!(fabs(qf) < 2147483648.0)) return fmod(t, td);
+    double r = t - qf * td;
+    if ((t >= 0 && r < 0) || (t < 0 && r > 0)) r = t - (qf - (t >= 0 ? 1.0 : -1.0)) * td;
+    return r;
+}
+
 // laser_models.py:167-184: LUT index of beam b.  The reference advances theta_index by
 // num_beams sequential fp64 adds (wrapping at theta_dis); in 24.40 fixed point
 // T0 + b*INC differs from that recurrence by < 1e-9, so the integer part agrees unless
@@ -202,10 +216,14 @@ template <bool IDENT, bool POW2, bool STEP>
 #endif
 __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel(ScanArgs a)
 {
-    __shared__ double s_lut[LUT_LDS];
+    __shared__ __attribute__((aligned(16))) double s_lut[LUT_LDS];
     __shared__ int s_chunk0[MAX_CHUNKS];
     const int nb = a.scan.nb;
-    for (int i = threadIdx.x; i < LUT_LDS; i += SCAN_THREADS) s_lut[i] = i < (int)CODE_BORDER ? a.map.lut[i] : a.map.oob;
+    {   // LDS image of the LUT prepared by the host (slot CODE_BORDER = dt[-1,-1]): 16-B copies
+        const double2 *src = reinterpret_cast<const double2 *>(a.map.lut_lds);
+        double2 *dst = reinterpret_cast<double2 *>(s_lut);
+        for (int i = threadIdx.x; i < LUT_LDS / 2; i += SCAN_THREADS) dst[i] = src[i];
+    }
     for (int i = threadIdx.x; i < ((nb + 63) >> 6); i += SCAN_THREADS) s_chunk0[i] = a.chunk_beam0[i];
     __syncthreads();
     MapView mv;
@@ -271,7 +289,7 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
     } else {
         const double td = (double)a.scan.theta_dis;
         double t0w = td * (yaw - a.scan.fov / 2.) / (2. * F110_PI);
-        t0w = fmod(t0w, td);
+        t0w = fmod_small(t0w, td);
         while (t0w < 0) t0w += td;
         // 24.40 fixed point of t0w in [0, theta_dis); a NaN / out-of-range yaw falls to the slow path
         const unsigned long long T0 = (t0w >= 0 && t0w < td) ? (unsigned long long)(t0w * 1099511627776.0) : ~0ull;

@@ -188,3 +188,14 @@ def test_raycast_golden(eng, golden):
     assert np.array_equal(span, g['span'])
     assert np.allclose(out, g['scans_out'], rtol=0, atol=1e-9)
     assert np.array_equal(out != scans_in, g['scans_out'] != scans_in)
+
+
+def test_scan_yaw_extremes_vs_oracle(eng, ex_oracle):
+    """fmod / LUT-index start for yaws far outside [0, 2pi), exact multiples of the LUT
+    step and sign changes (laser_models.py:167-172)."""
+    rng = np.random.default_rng(21)
+    yaws = np.concatenate([[0.0, -0.0, np.pi, -np.pi, 2 * np.pi, -2 * np.pi, 1e-300, -1e-300, 1e6, -1e6, 12345.678, -9876.54],
+                           2 * np.pi * rng.integers(-50, 50, 20) / 2000.0 + np.pi,   # exact LUT-bin boundaries
+                           rng.uniform(-200, 200, 60)])
+    poses = np.stack([np.full_like(yaws, 0.7), np.zeros_like(yaws), yaws], axis=1)
+    assert np.array_equal(_np(eng.scan(poses)), ex_oracle.scan_batch(poses))
