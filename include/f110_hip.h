@@ -172,6 +172,11 @@ int f110_scan(f110_handle *h, const double *poses, int32_t n, double *scans_f64,
 /* RaceCar.update_pose without the scan (base_classes.py:254-402), n cars in place. */
 int f110_update_pose(f110_handle *h, double *state, double *steer_buf, int32_t *steer_cnt,
                      const double *actions, int32_t n, void *stream);
+/* vehicle_dynamics_st (dynamic_models.py:124-176; kinematic == 1: vehicle_dynamics_ks
+ * :91-121 on the first 5 states): right-hand sides f [n,7] for states x [n,7] and inputs
+ * u [n,2] = (steering velocity, acceleration), with the handle's agent-0 parameters. */
+int f110_vehicle_dynamics(f110_handle *h, const double *x, const double *u, int32_t n, int32_t kinematic,
+                          double *f, void *stream);
 /* get_vertices (collision_models.py:238-260): [n,3] -> [n,4,2] */
 int f110_get_vertices(f110_handle *h, const double *poses, int32_t n, double *verts, void *stream);
 /* collision (GJK, collision_models.py:114-182) on n quad pairs -> hit[n] */

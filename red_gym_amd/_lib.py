@@ -56,6 +56,7 @@ SYMBOLS = {
     'f110_profile_end': [_VP, C.POINTER(C.c_double), C.POINTER(C.c_int32)],
     'f110_scan': [_VP, _VP, _I32, _VP, _VP, _VP, _VP],
     'f110_update_pose': [_VP, _VP, _VP, _VP, _VP, _I32, _VP],
+    'f110_vehicle_dynamics': [_VP, _VP, _VP, _I32, _I32, _VP, _VP],
     'f110_get_vertices': [_VP, _VP, _I32, _VP, _VP],
     'f110_gjk_pairs': [_VP, _VP, _VP, _I32, _VP, _VP],
     'f110_collision_multiple': [_VP, _VP, _I32, _I32, _VP, _VP, _VP],

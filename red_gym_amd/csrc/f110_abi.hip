@@ -676,6 +676,17 @@ extern "C" int f110_update_pose(f110_handle *h, double *state, double *steer_buf
     return F110_OK;
 }
 
+extern "C" int f110_vehicle_dynamics(f110_handle *h, const double *x, const double *u, int32_t n, int32_t kinematic,
+                                     double *f, void *stream)
+{
+    if (h && n == 0) return F110_OK;
+    if (!h || !x || !u || !f || n < 0) return fail(F110_E_INVALID, "f110_vehicle_dynamics: bad arguments");
+    hipLaunchKernelGGL(rhs_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, u, n, kinematic,
+                       h->d_agent_params, f);
+    HIP_TRY(hipGetLastError());
+    return F110_OK;
+}
+
 extern "C" int f110_get_vertices(f110_handle *h, const double *poses, int32_t n, double *verts, void *stream)
 {
     if (h && n == 0) return F110_OK;

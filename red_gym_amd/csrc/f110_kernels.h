@@ -634,6 +634,27 @@ __global__ __launch_bounds__(128) void env_kernel(EnvArgs a)
 }
 
 // ------------------------------------------------------------------ function-level kernels
+// dynamic_models.py:91-121 / :124-176 right-hand sides (the reference's KAT surface)
+__global__ void rhs_kernel(const double *x, const double *u, int n, int kinematic, const Params *agent_params, double *f)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Params P = agent_params[0];
+    double xs[7], fs[7];
+    for (int k = 0; k < 7; k++) xs[k] = x[(size_t)i * 7 + k];
+    if (kinematic) {
+        const double *p = P.v;
+        const double lwb = p[P_LF] + p[P_LR];
+        const double u0 = steering_constraint(xs[2], u[2 * i], p[P_SMIN], p[P_SMAX], p[P_SVMIN], p[P_SVMAX]);
+        const double u1 = accl_constraints(xs[3], u[2 * i + 1], p[P_VSWITCH], p[P_AMAX], p[P_VMIN], p[P_VMAX]);
+        fs[0] = xs[3] * cos(xs[4]); fs[1] = xs[3] * sin(xs[4]); fs[2] = u0; fs[3] = u1; fs[4] = xs[3] / lwb * tan(xs[2]);
+        fs[5] = 0; fs[6] = 0;
+    } else {
+        vehicle_dynamics_st(xs, u[2 * i], u[2 * i + 1], P, fs);
+    }
+    for (int k = 0; k < 7; k++) f[(size_t)i * 7 + k] = fs[k];
+}
+
 __global__ void vertices_kernel(const double *poses, int n, double L, double W, double *out)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -260,6 +260,14 @@ class Engine(object):
                                              state.shape[0], self._stream()))
         return state, steer_buf, cnt
 
+    def vehicle_dynamics(self, x, u, kinematic=False):
+        """dynamic_models.py:124-176 (or :91-121): f(x, u) with agent 0's parameters."""
+        x, u = self._dev64(x, (-1, 7)), self._dev64(u, (-1, 2))
+        f = torch.empty_like(x)
+        _lib.check(self.lib.f110_vehicle_dynamics(self._h, _ptr(x), _ptr(u), x.shape[0], int(bool(kinematic)), _ptr(f),
+                                                  self._stream()))
+        return f
+
     def get_vertices(self, poses):
         poses = self._dev64(poses, (-1, 3))
         out = torch.empty((poses.shape[0], 4, 2), dtype=torch.float64, device=self.device)
