@@ -472,18 +472,18 @@ static int launch_scan_t(f110_handle *h, const ScanArgs &a, hipStream_t st)
     return F110_OK;
 }
 
-// Waves per car.  Measured on MI355X (profiles/r01g): splitting a car's beams over 2/4/8
-// waves does not pay even at 4 096 cars (0.119 / 0.113 / 0.122 / 0.149 ms) -- per-wave
-// prologue and the shorter queues' tails eat the extra parallelism -- so one wave per car
-// is the default; F110_WPC overrides it for experiments.
+// Waves per car.  Measured on MI355X (profiles/r01g, r01i): a wave's lifetime is bounded
+// below by its longest ray (~50 us), so splitting a car's beams over several waves only
+// pays while the chip is nearly empty: scan time at 256 / 1024 cars 76 -> 49 us and
+// 87 -> 65 us with 8 waves per car, but 121 -> 143 us at 4096 cars (prologues and the
+// shorter queues' tails eat the extra parallelism).  F110_WPC overrides the choice.
 static int waves_per_car(int n_cars, int num_beams)
 {
     static const char *env = getenv("F110_WPC");
-    int wpc = env ? atoi(env) : 1;
+    int wpc = env ? atoi(env) : (n_cars <= 1024 ? 8 : (n_cars <= 2048 ? 4 : 1));
     if (wpc != 2 && wpc != 4 && wpc != 8) wpc = 1;
     const int nch = (num_beams + 63) / 64;
     while (wpc > 1 && wpc > nch) wpc /= 2;
-    (void)n_cars;
     return wpc;
 }
 
