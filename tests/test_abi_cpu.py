@@ -89,3 +89,11 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert 'import oracle' not in src and 'from oracle' not in src, f
                 assert 'f110_oracle' not in src, f
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    """No fallback: without libf110_hip.so the import path raises and names the build command."""
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'nope' / 'libf110_hip.so'))
+    with pytest.raises(ImportError, match='no CPU fallback'):
+        _lib.load()
