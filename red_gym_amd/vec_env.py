@@ -88,6 +88,22 @@ class F110VecEnv(object):
         self.eng.step(self._as_dev(actions, 2))
         return self._result()
 
+    # ------------------------------------------------------------------ checkpoint / resume
+    _STATE_KEYS = ('state', 'steer_buf', 'steer_cnt', 'noise_step', 'spawn', 'start_rot', 'near_start', 'toggles',
+                   'current_time', 'pending_reset', 'collisions', 'collision_idx', 'in_collision', 'lap_counts',
+                   'lap_times', 'done', 'checkpoint_done', 'scans')
+
+    def state_dict(self):
+        """Everything a step depends on lives in the caller-owned tensors bound to the handle
+        (f110_buffers): a copy of them is a complete checkpoint of all B envs."""
+        return {k: self.eng.t[k].clone() for k in self._STATE_KEYS if self.eng.t[k] is not None}
+
+    def load_state_dict(self, sd):
+        for k, v in sd.items():
+            self.eng.t[k].copy_(v)
+        # the host's upper bound of any car's noise row must cover the restored counters
+        self.eng.host_steps_bound = max(self.eng.host_steps_bound, int(self.eng.t['noise_step'].max().item()) + 1)
+
     # ------------------------------------------------------------------ hipGraph replay
     def capture_step(self, policy=None):
         """Captures one step (optionally preceded by a device-side policy that fills the

@@ -325,3 +325,27 @@ def test_step_path_odd_configs_vs_oracle(assets, cfg):
             assert bool(_np(done)[b]) == oo[b]['done'], (k, b)
             assert np.array_equal(_np(info['toggles'])[b].astype(np.float64), oo[b]['toggles']), (k, b)
     env.close()
+
+
+def test_checkpoint_resume(assets):
+    """state_dict()/load_state_dict(): a rollout resumed from a checkpoint (in a fresh env)
+    continues bit-identically."""
+    import torch
+    from red_gym_amd import workload
+    B, A = 64, 2
+    poses = workload.spawn_poses(B, A)
+    acts = torch.as_tensor(workload.action_pool(30, B, A))
+    e1 = _vec(assets, B, A, autoreset=True)
+    e1.reset(poses)
+    for k in range(12):
+        e1.step(acts[k])
+    ck = e1.state_dict()
+    for k in range(12, 30):
+        obs1, _, d1, _ = e1.step(acts[k])
+    e2 = _vec(assets, B, A, autoreset=True)
+    e2.load_state_dict(ck)
+    for k in range(12, 30):
+        obs2, _, d2, _ = e2.step(acts[k])
+    assert torch.equal(e1.state, e2.state) and torch.equal(obs1['scans'], obs2['scans']) and torch.equal(d1, d2)
+    assert torch.equal(e1.eng.t['toggles'], e2.eng.t['toggles']) and torch.equal(e1.eng.t['lap_times'], e2.eng.t['lap_times'])
+    e1.close(); e2.close()
