@@ -107,9 +107,20 @@ class F110Env(_Base):
         F110Env.render_callbacks.append(callback_func)
 
     def render(self, mode='human'):
-        """The pyglet/OpenGL window of the reference (rendering.py) is out of scope; the
-        call is accepted (callers invoke it every step) and does nothing."""
+        """The pyglet/OpenGL window of the reference (rendering.py) is out of scope.  The call
+        is accepted (callers invoke it every step); with `env.start_recording(max_steps)` it
+        logs the frame the window would have shown (poses, laps) for `env.save_recording()`."""
         assert mode in ['human', 'human_fast']
+        if getattr(self, '_recorder', None) is not None and self._recorder.t < self._recorder.max_steps:
+            self._recorder.record()
+
+    def start_recording(self, max_steps, with_scans=False):
+        from .recorder import TrajectoryRecorder
+        self._recorder = TrajectoryRecorder(self._vec, max_steps, with_scans=with_scans)
+        return self._recorder
+
+    def save_recording(self, path):
+        return self._recorder.save(path)
 
     def close(self):
         self._vec.close()

@@ -123,3 +123,36 @@ def test_hip_pure_pursuit_matches_numpy_planner(assets):
     assert np.allclose(s[0, 0], oo['state'][0], rtol=0, atol=1e-7) and np.array_equal(s[0], s[15])
     assert s[0, 0, 3] > 5.0  # racing, not crashed
     env.close(); env2.close()
+
+
+def test_trajectory_recorder(assets, tmp_path):
+    """Headless replacement of the render window: records poses / laps (and scans) on the
+    device and dumps an .npz that replays the run."""
+    from red_gym_amd import F110Env, F110VecEnv, workload
+    from red_gym_amd.recorder import TrajectoryRecorder
+    env = F110VecEnv(32, map=workload.EXAMPLE_MAP, num_agents=2, autoreset=True)
+    rec = TrajectoryRecorder(env, max_steps=20, envs=[3, 7, 31], with_scans=True)
+    poses, acts = workload.spawn_poses(32, 2), workload.action_pool(20, 32, 2)
+    env.reset(poses)
+    rec.record()
+    for k in range(19):
+        env.step(acts[k])
+        rec.record()
+    with pytest.raises(IndexError):
+        rec.record()
+    path = rec.save(str(tmp_path / 'traj.npz'))
+    d = np.load(path)
+    assert d['state'].shape == (20, 3, 2, 7) and d['scans'].shape == (20, 3, 2, 1080) and list(d['env_index']) == [3, 7, 31]
+    assert np.array_equal(d['state'][-1], env.state[[3, 7, 31]].cpu().numpy())
+    assert np.allclose(d['state'][0, :, :, 0:2], poses[[3, 7, 31], :, 0:2])
+    env.close()
+    e1 = F110Env(map=os.path.join(assets, 'example_map'), num_agents=1)
+    e1.start_recording(5)
+    obs, *_ = e1.reset(np.array([[0.7, 0.0, 1.37]]))
+    e1.render()
+    for _ in range(3):
+        obs, *_ = e1.step(np.array([[0.0, 1.0]]))
+        e1.render(mode='human_fast')
+    out = np.load(e1.save_recording(str(tmp_path / 'single.npz')))
+    assert out['state'].shape == (4, 1, 1, 7) and abs(out['state'][-1, 0, 0, 0] - obs['poses_x'][0]) < 1e-15
+    e1.close()
