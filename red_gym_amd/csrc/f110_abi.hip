@@ -337,25 +337,41 @@ static int install_map(f110_handle *h, const double *dt, const uint32_t *d2_or_n
     const int strips = (W + 2 + 7) >> 3, Hp = ((H + 2 + 7) >> 3) << 3;
     const size_t n_tiled = (size_t)strips * Hp * 8;
     std::vector<uint16_t> cells(n_tiled, (uint16_t)CODE_BORDER);
+    // exact squared distance of every cell (ESC64: not of the form resolution*sqrt(integer))
+    const uint64_t ESC64 = ~0ull;
+    std::vector<uint64_t> d2v(n);
     for (size_t i = 0; i < n; i++) {
         uint64_t d2;
         if (d2_or_null) d2 = d2_or_null[i];
         else {
             double q = dt[i] / res;
             double r = std::nearbyint(q * q);
-            d2 = (r >= 0 && r < 4.0e18) ? (uint64_t)r : (uint64_t)CODE_ESC;
-            if (d2 < (uint64_t)CODE_ESC && res * std::sqrt((double)d2) != dt[i]) d2 = CODE_ESC;
+            d2 = (r >= 0 && r < 4.0e18) ? (uint64_t)r : ESC64;
+            if (d2 != ESC64 && res * std::sqrt((double)d2) != dt[i]) d2 = ESC64;
         }
+        d2v[i] = d2;
+    }
+    // Codes are RANKS among the distinct d2 values of this map (ascending), not d2 itself:
+    // squared distances are sums of two squares, so the 1023 LDS slots reach d2 ~ 3 900
+    // (62 cells) instead of 1 022 (32 cells) -- the middle of a 5 m wide road still hits LDS.
+    std::vector<uint64_t> distinct(d2v);
+    std::sort(distinct.begin(), distinct.end());
+    distinct.erase(std::unique(distinct.begin(), distinct.end()), distinct.end());
+    if (!distinct.empty() && distinct.back() == ESC64) distinct.pop_back();
+    const size_t n_lut = std::max<size_t>(LUT_LDS, std::min<size_t>(distinct.size(), CODE_ESC - 1)); // ranks 0..65533 are encodable
+    std::vector<double> lut(n_lut, 0.0);
+    for (size_t k = 0; k < n_lut && k < distinct.size(); k++) lut[k] = res * std::sqrt((double)distinct[k]);
+    for (size_t i = 0; i < n; i++) {
         const size_t r = i / W + 1, c = i % W + 1;
         const size_t t = ((c >> 3) * (size_t)Hp + r) * 8 + (c & 7);
-        uint16_t code;
-        if (d2 < CODE_BORDER) code = (uint16_t)d2;
-        else if (d2 <= 65533) code = (uint16_t)(d2 + 1);
-        else code = (uint16_t)CODE_ESC;
+        uint16_t code = (uint16_t)CODE_ESC;
+        if (d2v[i] != ESC64) {
+            const size_t rank = std::lower_bound(distinct.begin(), distinct.end(), d2v[i]) - distinct.begin();
+            if (rank < CODE_BORDER) code = (uint16_t)rank;
+            else if (rank <= 65533) code = (uint16_t)(rank + 1);
+        }
         cells[t] = code;
     }
-    std::vector<double> lut(CODE_ESC);
-    for (int i = 0; i < CODE_ESC; i++) lut[i] = res * std::sqrt((double)i);
     HIP_TRY(hipSetDevice(h->cfg.device));
     HIP_TRY(hipDeviceSynchronize()); // the previous map may still be in use by enqueued steps
     if (h->d_cells) { (void)hipFree(h->d_cells); h->d_cells = nullptr; }

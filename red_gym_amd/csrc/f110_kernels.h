@@ -36,9 +36,10 @@ constexpr int SCAN_THREADS = SCAN_WAVES * WAVE;
 constexpr int REFILL_MIN_IDLE = F110_REFILL_MIN_IDLE; // refill the wave's beam slots once this many lanes idle
 
 // Cell table.  Each map cell stores a 16-bit code of its exact squared distance d2 (in
-// cells) to the nearest obstacle: code = d2 for d2 < 1023, d2 + 1 for 1023 <= d2 <= 65533,
-// CODE_ESC otherwise (also for cells of a user table that are not resolution*sqrt(int));
-// the distance itself comes from a fp64 LUT (first 1023 entries in LDS).  The table has a
+// cells) to the nearest obstacle: the RANK k of d2 among the distinct d2 values of the map
+// (code = k for k < 1023, k + 1 for 1023 <= k <= 65533), CODE_ESC otherwise (also for cells
+// of a user table that are not resolution*sqrt(int)); the distance itself comes from a fp64
+// LUT lut[k] = resolution*sqrt(d2_k) (first 1023 entries in LDS, i.e. d2 up to ~3 900).  The table has a
 // one-cell BORDER on every side holding CODE_BORDER, whose LDS slot holds dt[-1,-1]: the
 // reference's out-of-bounds read (laser_models.py:80-81,:103) becomes an ordinary lookup
 // of a clamped index -- no bounds compare, no select in the march loop.
@@ -58,7 +59,7 @@ struct MapDev {
     const uint16_t *cells;  // padded strips [ceil((W+2)/8)][Hp][8]
     unsigned cells_bytes;
     unsigned strip_bytes;   // Hp * 16, Hp = H + 2 rounded up to a multiple of 8
-    const double *lut;      // [65534] resolution*sqrt(d2), indexed by d2
+    const double *lut;      // [<=65534] resolution*sqrt(d2_k), indexed by rank k
     const double *lut_lds;  // [LUT_LDS] image staged in LDS: lut[0..CODE_BORDER-1], then dt[-1,-1]
     const double *dt;       // [H*W] exact fp64 distance table (escape path, rarely touched)
     int H, W;
