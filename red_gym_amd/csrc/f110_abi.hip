@@ -50,11 +50,11 @@ struct f110_handle {
     double2 *d_cs = nullptr;          // interleaved {cos, sin} LUT (repeated, see upload_cs)
     int cs_len = 0;
     double2 *d_beam_cs = nullptr;     // {cos, sin}(scan_angles) for the opponent ray cast
-    double *d_zero_row = nullptr;     // noise row used when noise is off
     std::vector<double> h_sines, h_cosines;
     double *d_lut = nullptr, *d_lut_lds = nullptr, *d_dt = nullptr;
-    double *d_noise = nullptr;
+    double2 *d_noise_side = nullptr;  // [max(T,1), nb] {noise, side distance}
     long long noise_T = 0;
+    std::vector<double> h_noise, h_side; // host copies the interleaved table is rebuilt from
     MapDev map;
     bool ident = false, pow2 = false;
     double theta_inc = 0;
@@ -209,6 +209,7 @@ static int upload_beam_cs(f110_handle *h, const double *scan_angles)
 }
 
 static int upload_agent_params(f110_handle *h);
+static int rebuild_noise_side(f110_handle *h);
 
 // scratch of the opponent ray cast: allocated here, never in f110_step
 static int alloc_opp_pairs(f110_handle *h)
@@ -268,8 +269,8 @@ extern "C" int f110_create(const f110_config *cfg, f110_handle **out)
     int rc;
     h->h_sines = s;
     h->h_cosines = c;
-    std::vector<double> zeros(cfg->num_beams, 0.0);
-    if ((rc = upload_cs(h)) || (rc = upload(&h->d_zero_row, zeros.data(), zeros.size())) ||
+    h->h_side = side;
+    if ((rc = upload_cs(h)) || (rc = rebuild_noise_side(h)) ||
         (rc = upload(&h->d_scan_angles, ang.data(), ang.size())) || (rc = upload_beam_cs(h, ang.data())) ||
         (rc = upload(&h->d_beam_cosines, bcos.data(), bcos.size())) ||
         (rc = upload(&h->d_side, side.data(), side.size())) || (rc = set_beam_order(h)) || (rc = upload_agent_params(h)) || (rc = alloc_opp_pairs(h))) {
@@ -284,8 +285,8 @@ extern "C" void f110_destroy(f110_handle *h)
 {
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
-    void *ptrs[] = {h->d_cs, h->d_beam_cs, h->d_zero_row, h->d_scan_angles, h->d_beam_cosines, h->d_side,
-                    h->d_cells, h->d_lut, h->d_lut_lds, h->d_dt, h->d_noise, h->d_chunk0, h->d_agent_params, h->d_opp_pairs};
+    void *ptrs[] = {h->d_cs, h->d_beam_cs, h->d_noise_side, h->d_scan_angles, h->d_beam_cosines, h->d_side,
+                    h->d_cells, h->d_lut, h->d_lut_lds, h->d_dt, h->d_chunk0, h->d_agent_params, h->d_opp_pairs};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
@@ -322,7 +323,11 @@ extern "C" int f110_set_tables(f110_handle *h, const double *sines, const double
     if ((sines || cosines) && (rc = upload_cs(h))) return rc;
     if (ang && ((rc = upload(&h->d_scan_angles, ang, h->cfg.num_beams)) || (rc = upload_beam_cs(h, ang)))) return rc;
     if (bcos && (rc = upload(&h->d_beam_cosines, bcos, h->cfg.num_beams))) return rc;
-    if (side && (rc = upload(&h->d_side, side, h->cfg.num_beams))) return rc;
+    if (side) {
+        if ((rc = upload(&h->d_side, side, h->cfg.num_beams))) return rc;
+        h->h_side.assign(side, side + h->cfg.num_beams);
+        if ((rc = rebuild_noise_side(h))) return rc;
+    }
     return rc;
 }
 
@@ -443,12 +448,28 @@ extern "C" int f110_set_noise_table(f110_handle *h, const double *tbl, int64_t T
     if (T < 0 || (T > 0 && !tbl)) return fail(F110_E_INVALID, "f110_set_noise_table: bad table");
     HIP_TRY(hipSetDevice(h->cfg.device));
     HIP_TRY(hipDeviceSynchronize());
-    if (h->d_noise) { (void)hipFree(h->d_noise); h->d_noise = nullptr; }
-    h->noise_T = 0;
-    if (T == 0) return F110_OK;
-    const size_t n = (size_t)T * h->cfg.num_beams;
-    HIP_TRY(hipMalloc((void **)&h->d_noise, n * sizeof(double)));
-    HIP_TRY(hipMemcpy(h->d_noise, tbl, n * sizeof(double), hipMemcpyHostToDevice));
+    h->h_noise.clear();
+    if (T > 0) h->h_noise.assign(tbl, tbl + (size_t)T * h->cfg.num_beams);
+    return rebuild_noise_side(h);
+}
+
+// {noise row, side distance} interleaved per beam (noise off: one row of zeros)
+static int rebuild_noise_side(f110_handle *h)
+{
+    const int nb = h->cfg.num_beams;
+    const long long T = (long long)(h->h_noise.size() / nb);
+    const long long rows = T > 0 ? T : 1;
+    std::vector<double2> ns((size_t)rows * nb);
+    for (long long t = 0; t < rows; t++)
+        for (int i = 0; i < nb; i++) {
+            ns[(size_t)t * nb + i].x = T > 0 ? h->h_noise[(size_t)t * nb + i] : 0.0;
+            ns[(size_t)t * nb + i].y = h->h_side[i];
+        }
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    HIP_TRY(hipDeviceSynchronize()); // enqueued steps may still read the old table
+    if (h->d_noise_side) { (void)hipFree(h->d_noise_side); h->d_noise_side = nullptr; }
+    HIP_TRY(hipMalloc((void **)&h->d_noise_side, ns.size() * sizeof(double2)));
+    HIP_TRY(hipMemcpy(h->d_noise_side, ns.data(), ns.size() * sizeof(double2), hipMemcpyHostToDevice));
     h->noise_T = T;
     return F110_OK;
 }
@@ -528,8 +549,8 @@ static int run_step(f110_handle *h, const double *actions, int reset_only, hipSt
     s.map = h->map; s.scan = scan_dev(h); s.n_cars = N; s.agents = c.num_agents;
     s.pose_src = b.state; s.pose_stride = 7; s.yaw_off = 4;
     s.state = b.state; s.noise_step = b.noise_step; s.chunk_beam0 = h->d_chunk0;
-    s.noise = h->noise_T > 0 ? h->d_noise : h->d_zero_row; s.noise_T = h->noise_T > 0 ? h->noise_T : 1;
-    s.beam_cosines = h->d_beam_cosines; s.side_distances = h->d_side;
+    s.noise_side = h->d_noise_side; s.noise_T = h->noise_T > 0 ? h->noise_T : 1;
+    s.beam_cosines = h->d_beam_cosines;
     s.ttc_thresh = c.ttc_thresh;
     s.in_collision = b.in_collision; s.pending_reset = b.pending_reset; s.reset_only = reset_only;
     s.out_f32 = b.scans; s.out_f64 = b.scans_f64; s.lookups = b.lookups;

@@ -190,9 +190,9 @@ struct ScanArgs {
     // full-step extras (all NULL for the function-level scan)
     const double *state;         // [N,7]: velocity for the iTTC test
     const int32_t *noise_step;   // [N]
-    const double *noise;         // [T,nb] or NULL
+    const double2 *noise_side;   // [T,nb] {noise of row t, side distance} interleaved: one 16-B gather per finished beam
     long long noise_T;
-    const double *beam_cosines, *side_distances; // [nb]
+    const double *beam_cosines;  // [nb]
     double ttc_thresh;
     uint8_t *in_collision;       // [N]
     const uint8_t *pending_reset;// [B]
@@ -254,8 +254,7 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
     // iTTC hit needs 0 <= (v - side)/(vel*cos) < thresh, hence |v - side| < thresh*|vel|:
     // only such candidate beams pay the exact fp64 division
     const double cand = a.ttc_thresh * fabs(vel) * 1.000000001;
-    const double *nz = STEP ? a.noise + (size_t)((long long)a.noise_step[car] % a.noise_T) * nb : nullptr;
-    const double *__restrict__ side = a.side_distances;
+    const double2 *__restrict__ ns = STEP ? a.noise_side + (size_t)((long long)a.noise_step[car] % a.noise_T) * nb : nullptr;
     float *o32 = a.out_f32 ? a.out_f32 + (size_t)car * nb : nullptr;
     double *o64 = a.out_f64 ? a.out_f64 + (size_t)car * nb : nullptr;
     bool hit = false;
@@ -285,7 +284,8 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
     if (!(d0 > eps && d0 <= max_range)) {
         for (int k = lane; k < nbl; k += WAVE) {
             const int i = s_chunk0[(k >> 6) * wpc + part] + (k & 63);
-            emit(i, d0, STEP ? nz[i] : 0.0, STEP ? side[i] : 0.0);
+            const double2 v = STEP ? ns[i] : make_double2(0.0, 0.0);
+            emit(i, d0, v.x, v.y);
         }
     } else {
         const double td = (double)a.scan.theta_dis;
@@ -306,9 +306,10 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
             if (!active) {
                 // all independent loads first (one memory round trip): the finished beam's
                 // noise / side distance and the new beam's number
-                const unsigned pb8 = (unsigned)(beam < 0 ? 0 : beam) * 8u; // 32-bit byte offset: scalar base + VGPR offset
-                const double nzv = STEP ? *reinterpret_cast<const double *>(reinterpret_cast<const char *>(nz) + (size_t)pb8) : 0.0;
-                const double sdv = STEP ? *reinterpret_cast<const double *>(reinterpret_cast<const char *>(side) + (size_t)pb8) : 0.0;
+                const unsigned pb16 = (unsigned)max(beam, 0) * 16u; // 32-bit byte offset: scalar base + VGPR offset
+                const double2 nsv = STEP ? *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(ns) + (size_t)pb16)
+                                         : make_double2(0.0, 0.0);
+                const double nzv = nsv.x, sdv = nsv.y;
                 const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32),
                                     __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
                 const int k = next + rank;
