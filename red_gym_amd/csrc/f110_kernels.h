@@ -73,10 +73,12 @@ struct MapView {
     const double *lut, *dt;
     int H, W;
     double res, rinv, ox, oy, oc, os, wres, hres;
+    double nox, noy; // -ox * rinv, -oy * rinv (exact when rinv is a power of two)
     __device__ void init(const MapDev &m)
     {
         strip_bytes = m.strip_bytes; lut = m.lut; dt = m.dt; H = m.H; W = m.W; res = m.res; rinv = m.rinv;
         ox = m.ox; oy = m.oy; oc = m.oc; os = m.os; wres = m.wres; hres = m.hres;
+        nox = -m.ox * m.rinv; noy = -m.oy * m.rinv;
     }
 };
 
@@ -96,11 +98,20 @@ struct ScanDev {
 template <bool IDENT, bool POW2>
 __device__ inline double dist_lookup(const MapView &m, const double *lds_lut, double x, double y, bool live)
 {
-    const double xt = x - m.ox, yt = y - m.oy;
-    double xr, yr;
-    if (IDENT) { xr = xt; yr = yt; }
-    else { xr = xt * m.oc + yt * m.os; yr = -xt * m.os + yt * m.oc; }
-    const double qx = xr * m.rinv, qy = yr * m.rinv;
+    double xr = 0, yr = 0, qx, qy;
+    if (IDENT && POW2) {
+        // q = (x - ox) * 2^k is ONE fma: scaling by a power of two commutes with rounding, so
+        // fma(x, 2^k, -ox*2^k) == fl(x - ox) * 2^k bit for bit (the reference's two roundings
+        // collapse because the second is exact).  Explicit fma: contraction stays off.
+        qx = __builtin_fma(x, m.rinv, m.nox);
+        qy = __builtin_fma(y, m.rinv, m.noy);
+    } else {
+        const double xt = x - m.ox, yt = y - m.oy;
+        if (IDENT) { xr = xt; yr = yt; }
+        else { xr = xt * m.oc + yt * m.os; yr = -xt * m.os + yt * m.oc; }
+        qx = xr * m.rinv;
+        qy = yr * m.rinv;
+    }
     const double fx = floor(qx), fy = floor(qy);
     int ci = (int)fx, ri = (int)fy; // saturating conversion; the clamp below finishes the job
     if (!POW2) {
