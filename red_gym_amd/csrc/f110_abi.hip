@@ -46,7 +46,7 @@ struct f110_handle {
     f110_buffers bufs;
     // device tables owned by the handle
     double *d_scan_angles = nullptr, *d_beam_cosines = nullptr, *d_side = nullptr;
-    uint16_t *d_cells = nullptr, *d_chunk0 = nullptr;
+    uint16_t *d_cells = nullptr, *d_cells_far = nullptr, *d_chunk0 = nullptr;
     double2 *d_cs = nullptr;          // interleaved {cos, sin} LUT (repeated, see upload_cs)
     int cs_len = 0;
     double2 *d_beam_cs = nullptr;     // {cos, sin}(scan_angles) for the opponent ray cast
@@ -286,7 +286,7 @@ extern "C" void f110_destroy(f110_handle *h)
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
     void *ptrs[] = {h->d_cs, h->d_beam_cs, h->d_noise_side, h->d_scan_angles, h->d_beam_cosines, h->d_side,
-                    h->d_cells, h->d_lut, h->d_lut_lds, h->d_dt, h->d_chunk0, h->d_agent_params, h->d_opp_pairs};
+                    h->d_cells, h->d_cells_far, h->d_lut, h->d_lut_lds, h->d_dt, h->d_chunk0, h->d_agent_params, h->d_opp_pairs};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
@@ -341,7 +341,7 @@ static int install_map(f110_handle *h, const double *dt, const uint32_t *d2_or_n
     // padded table (one border cell on every side), 8-column strips: see MapDev
     const int strips = (W + 2 + 7) >> 3, Hp = ((H + 2 + 7) >> 3) << 3;
     const size_t n_tiled = (size_t)strips * Hp * 8;
-    std::vector<uint16_t> cells(n_tiled, (uint16_t)CODE_BORDER);
+    std::vector<uint16_t> cells(n_tiled, (uint16_t)OFF_BORDER), cells_far(n_tiled, 0);
     // exact squared distance of every cell (ESC64: not of the form resolution*sqrt(integer))
     const uint64_t ESC64 = ~0ull;
     std::vector<uint64_t> d2v(n);
@@ -363,35 +363,37 @@ static int install_map(f110_handle *h, const double *dt, const uint32_t *d2_or_n
     std::sort(distinct.begin(), distinct.end());
     distinct.erase(std::unique(distinct.begin(), distinct.end()), distinct.end());
     if (!distinct.empty() && distinct.back() == ESC64) distinct.pop_back();
-    const size_t n_lut = std::max<size_t>(LUT_LDS, std::min<size_t>(distinct.size(), CODE_ESC - 1)); // ranks 0..65533 are encodable
+    if (distinct.empty() || distinct.front() != 0) distinct.insert(distinct.begin(), 0); // rank 0 <-> 0.0 (parked rays)
+    const size_t n_lut = std::max<size_t>(LUT_LDS, std::min<size_t>(distinct.size(), CODE_ESC)); // ranks 0..65534 are encodable
     std::vector<double> lut(n_lut, 0.0);
     for (size_t k = 0; k < n_lut && k < distinct.size(); k++) lut[k] = res * std::sqrt((double)distinct[k]);
     for (size_t i = 0; i < n; i++) {
         const size_t r = i / W + 1, c = i % W + 1;
         const size_t t = ((c >> 3) * (size_t)Hp + r) * 8 + (c & 7);
-        uint16_t code = (uint16_t)CODE_ESC;
-        if (d2v[i] != ESC64) {
-            const size_t rank = std::lower_bound(distinct.begin(), distinct.end(), d2v[i]) - distinct.begin();
-            if (rank < CODE_BORDER) code = (uint16_t)rank;
-            else if (rank <= 65533) code = (uint16_t)(rank + 1);
-        }
-        cells[t] = code;
+        size_t rank = CODE_ESC;
+        if (d2v[i] != ESC64) rank = std::min<size_t>(std::lower_bound(distinct.begin(), distinct.end(), d2v[i]) - distinct.begin(), CODE_ESC);
+        cells[t] = (uint16_t)(rank < SLOT_FAR ? 8 * rank : OFF_FAR);
+        cells_far[t] = (uint16_t)rank;
     }
     HIP_TRY(hipSetDevice(h->cfg.device));
     HIP_TRY(hipDeviceSynchronize()); // the previous map may still be in use by enqueued steps
     if (h->d_cells) { (void)hipFree(h->d_cells); h->d_cells = nullptr; }
+    if (h->d_cells_far) { (void)hipFree(h->d_cells_far); h->d_cells_far = nullptr; }
     if (h->d_dt) { (void)hipFree(h->d_dt); h->d_dt = nullptr; }
     HIP_TRY(hipMalloc((void **)&h->d_cells, n_tiled * sizeof(uint16_t)));
     HIP_TRY(hipMalloc((void **)&h->d_dt, n * sizeof(double)));
     HIP_TRY(hipMemcpy(h->d_cells, cells.data(), n_tiled * sizeof(uint16_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc((void **)&h->d_cells_far, n_tiled * sizeof(uint16_t)));
+    HIP_TRY(hipMemcpy(h->d_cells_far, cells_far.data(), n_tiled * sizeof(uint16_t), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->d_dt, dt, n * sizeof(double), hipMemcpyHostToDevice));
     int rc = upload(&h->d_lut, lut.data(), lut.size());
     if (rc) return rc;
     std::vector<double> lut_lds(lut.begin(), lut.begin() + LUT_LDS);
-    lut_lds[CODE_BORDER] = dt[n - 1]; // dt[-1, -1]
+    lut_lds[SLOT_FAR] = 0.0;          // never used as a distance (OFF_FAR cells take the second table)
+    lut_lds[SLOT_BORDER] = dt[n - 1]; // dt[-1, -1]
     if ((rc = upload(&h->d_lut_lds, lut_lds.data(), lut_lds.size()))) return rc;
     MapDev &m = h->map;
-    m.cells = h->d_cells; m.lut = h->d_lut; m.lut_lds = h->d_lut_lds; m.dt = h->d_dt;
+    m.cells = h->d_cells; m.cells_far = h->d_cells_far; m.lut = h->d_lut; m.lut_lds = h->d_lut_lds; m.dt = h->d_dt;
     m.H = H; m.W = W; m.strip_bytes = (unsigned)Hp * 16u; m.cells_bytes = (unsigned)(n_tiled * sizeof(uint16_t)); m.res = res; m.rinv = 1.0 / res;
     m.ox = ox; m.oy = oy; m.oc = oc; m.os = os;
     m.wres = W * res; // width * resolution (laser_models.py:79)

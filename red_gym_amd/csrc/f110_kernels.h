@@ -35,32 +35,34 @@ constexpr int SCAN_WAVES = F110_SCAN_WAVES;   // cars per workgroup (one wavefro
 constexpr int SCAN_THREADS = SCAN_WAVES * WAVE;
 constexpr int REFILL_MIN_IDLE = F110_REFILL_MIN_IDLE; // refill the wave's beam slots once this many lanes idle
 
-// Cell table.  Each map cell stores a 16-bit code of its exact squared distance d2 (in
-// cells) to the nearest obstacle: the RANK k of d2 among the distinct d2 values of the map
-// (code = k for k < 1023, k + 1 for 1023 <= k <= 65533), CODE_ESC otherwise (also for cells
-// of a user table that are not resolution*sqrt(int)); the distance itself comes from a fp64
-// LUT lut[k] = resolution*sqrt(d2_k) (first 1023 entries in LDS, i.e. d2 up to ~3 900).  The table has a
-// one-cell BORDER on every side holding CODE_BORDER, whose LDS slot holds dt[-1,-1]: the
-// reference's out-of-bounds read (laser_models.py:80-81,:103) becomes an ordinary lookup
-// of a clamped index -- no bounds compare, no select in the march loop.
+// Cell table.  Each map cell stores, as a u16, the BYTE OFFSET of its distance inside the LDS
+// copy of the LUT: 8*k, k = RANK of the cell's exact squared distance d2 (in cells, to the
+// nearest obstacle) among the distinct d2 values of the map, for k <= 1021 (squared
+// distances are sums of two squares, so that reaches d2 ~ 3 900 = 62 cells); OFF_FAR for
+// larger ranks and for cells of a user table that are not resolution*sqrt(int) -- those
+// re-read a second table (u16 rank, 65535 = "use the fp64 table") in a rarely taken branch.
+// Rank 0 is always d2 = 0, so LDS offset 0 is the distance 0.0.
+// The table has a one-cell BORDER on every side holding OFF_BORDER, whose LDS slot holds
+// dt[-1,-1]: the reference's out-of-bounds read (laser_models.py:80-81,:103) becomes an
+// ordinary lookup of a clamped index -- no bounds compare, no select, no index clamp or
+// scaling in the march loop (the loaded value addresses the ds_read directly).
 // Layout: 8-column strips, cell (r, c) of the padded table at [c >> 3][r][c & 7], so one
 // 128-B cache line holds an 8x8-cell block.  The 64 rays of a wave sample neighbouring
-// points, so a gather touches a few lines instead of one line per lane (row-major
-// measured ~40 distinct lines per 64-lane gather and made the kernel L1-tag-rate bound),
-// and the byte offset is one multiply-add: (c >> 3) * strip_bytes + r * 16 + (c & 7) * 2.
-#ifndef F110_LUT_LDS
-#define F110_LUT_LDS 1024
-#endif
-constexpr int LUT_LDS = F110_LUT_LDS;          // LDS LUT slots: d2 < LUT_LDS-1 plus the border slot
-constexpr unsigned CODE_BORDER = LUT_LDS - 1; // 1023
-constexpr unsigned CODE_ESC = 65535;          // read the fp64 table instead
+// points, so a gather touches fewer lines than with a row-major table (which measured
+// ~40 L1 accesses per 64-lane gather and made the kernel L1-tag-rate bound), and the byte
+// offset is one multiply-add: (c >> 3) * strip_bytes + r * 16 + (c & 7) * 2.
+constexpr int LUT_LDS = 1024;                           // LDS LUT slots
+constexpr unsigned SLOT_FAR = LUT_LDS - 2, SLOT_BORDER = LUT_LDS - 1;
+constexpr unsigned OFF_FAR = 8 * SLOT_FAR, OFF_BORDER = 8 * SLOT_BORDER;
+constexpr unsigned CODE_ESC = 65535;                    // second table: read the fp64 table instead
 
 struct MapDev {
-    const uint16_t *cells;  // padded strips [ceil((W+2)/8)][Hp][8]
+    const uint16_t *cells;  // padded strips [ceil((W+2)/8)][Hp][8] of LDS byte offsets
+    const uint16_t *cells_far; // same layout: rank (<= 65534) of the cells marked OFF_FAR, 65535 = fp64 table
     unsigned cells_bytes;
     unsigned strip_bytes;   // Hp * 16, Hp = H + 2 rounded up to a multiple of 8
     const double *lut;      // [<=65534] resolution*sqrt(d2_k), indexed by rank k
-    const double *lut_lds;  // [LUT_LDS] image staged in LDS: lut[0..CODE_BORDER-1], then dt[-1,-1]
+    const double *lut_lds;  // [LUT_LDS] image staged in LDS: lut[0..SLOT_FAR-1], unused, dt[-1,-1]
     const double *dt;       // [H*W] exact fp64 distance table (escape path, rarely touched)
     int H, W;
     double res, rinv, ox, oy, oc, os, wres, hres, oob; // oob = dt[H-1][W-1]
@@ -71,12 +73,13 @@ struct MapView {
     __amdgpu_buffer_rsrc_t cells_rsrc;
     unsigned strip_bytes;
     const double *lut, *dt;
+    const uint16_t *cells_far;
     int H, W;
     double res, rinv, ox, oy, oc, os, wres, hres;
     double nox, noy; // -ox * rinv, -oy * rinv (exact when rinv is a power of two)
     __device__ void init(const MapDev &m)
     {
-        strip_bytes = m.strip_bytes; lut = m.lut; dt = m.dt; H = m.H; W = m.W; res = m.res; rinv = m.rinv;
+        strip_bytes = m.strip_bytes; lut = m.lut; dt = m.dt; cells_far = m.cells_far; H = m.H; W = m.W; res = m.res; rinv = m.rinv;
         ox = m.ox; oy = m.oy; oc = m.oc; os = m.os; wres = m.wres; hres = m.hres;
         nox = -m.ox * m.rinv; noy = -m.oy * m.rinv;
     }
@@ -130,21 +133,28 @@ __device__ inline double dist_lookup(const MapView &m, const double *lds_lut, do
     }
     const int cc = med3_i32(ci, -1, m.W) + 1;  // padded column 0..W+1
     const int rr = med3_i32(ri, -1, m.H);      // padded row - 1 (the +1 is the +16 below)
-    unsigned off = __umul24((unsigned)cc >> 3, m.strip_bytes) + (((unsigned)rr << 4) + 16u) + (((unsigned)cc & 7u) << 1);
+    // byte offset of padded cell (rr + 1, cc): rows are 16 bytes inside a strip (the +16 of the
+    // border row rides in the shift-add, so the offset never goes negative)
+    unsigned row16; // (rr + 1) * 16 in one op; asm so that the +16 is not re-associated into a trailing add
+    asm("v_lshl_add_u32 %0, %1, 4, 16" : "=v"(row16) : "v"(rr));
+    unsigned off = __umul24((unsigned)cc >> 3, m.strip_bytes) + (row16 | (((unsigned)cc << 1) & 14u));
     // a finished ray presents an out-of-range offset: the hardware range check answers 0
-    // (= d2 0 = distance 0.0, which parks the ray: total += 0, x += 0*c) without occupying
-    // the L1 tag pipeline
+    // (= LDS offset 0 = distance 0.0, which parks the ray: total += 0, x += 0*c) without
+    // occupying the L1 tag pipeline
     off = live ? off : 0xffffffffu;
     // buffer load: 32-bit per-lane offset against a scalar descriptor
     const unsigned code = (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(m.cells_rsrc, (int)off, 0, 0);
-    // common case: one ds_read_b64 (d2 < 1023: within ~2 m of a wall; or the border slot)
-    double d = lds_lut[min(code, CODE_BORDER)];
+    // common case: the loaded value IS the LDS byte offset of the distance: one ds_read_b64
+    double d = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(lds_lut) + code);
     // pin the LDS read: otherwise the compiler folds it and the rare global reads below
     // into one flat_load through a selected generic pointer
     asm volatile("" : "+v"(d));
-    const bool far = code > CODE_BORDER;
+    const bool far = code == OFF_FAR;
     if (__builtin_expect(vote(far) != 0ull, 0)) {
-        if (far) d = (code != CODE_ESC) ? m.lut[code - 1u] : m.dt[(size_t)(unsigned)rr * (unsigned)m.W + (unsigned)(cc - 1)];
+        if (far) {
+            const unsigned rank = *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(m.cells_far) + (size_t)off);
+            d = (rank != CODE_ESC) ? m.lut[rank] : m.dt[(size_t)(unsigned)rr * (unsigned)m.W + (unsigned)(cc - 1)];
+        }
     }
     return d;
 }
@@ -231,7 +241,7 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
     __shared__ __attribute__((aligned(16))) double s_lut[LUT_LDS];
     __shared__ int s_chunk0[MAX_CHUNKS];
     const int nb = a.scan.nb;
-    {   // LDS image of the LUT prepared by the host (slot CODE_BORDER = dt[-1,-1]): 16-B copies
+    {   // LDS image of the LUT prepared by the host (slot SLOT_BORDER = dt[-1,-1]): 16-B copies
         const double2 *src = reinterpret_cast<const double2 *>(a.map.lut_lds);
         double2 *dst = reinterpret_cast<double2 *>(s_lut);
         for (int i = threadIdx.x; i < LUT_LDS / 2; i += SCAN_THREADS) dst[i] = src[i];

@@ -199,3 +199,22 @@ def test_scan_yaw_extremes_vs_oracle(eng, ex_oracle):
                            rng.uniform(-200, 200, 60)])
     poses = np.stack([np.full_like(yaws, 0.7), np.zeros_like(yaws), yaws], axis=1)
     assert np.array_equal(_np(eng.scan(poses)), ex_oracle.scan_batch(poses))
+
+
+def test_scan_rays_leaving_through_every_border(eng, ex_oracle):
+    """Poses just inside each edge of the map looking outwards and just outside looking in:
+    the clamped border lookups (dt[-1,-1], laser_models.py:80-81,:103) on all four sides and
+    the corners."""
+    m = ex_oracle.map
+    x0, y0 = m['orig_x'], m['orig_y']
+    x1, y1 = x0 + m['width'] * m['resolution'], y0 + m['height'] * m['resolution']
+    e = 0.03
+    pts = []
+    for x in (x0 - 5, x0 - e, x0 + e, 0.5 * (x0 + x1), x1 - e, x1 + e, x1 + 5):
+        for y in (y0 - 5, y0 - e, y0 + e, 0.5 * (y0 + y1), y1 - e, y1 + e, y1 + 5):
+            for yaw in (0.0, 1.0, 2.5, 4.0, 5.5):
+                pts.append((x, y, yaw))
+    poses = np.array(pts)
+    ref, rlk = ex_oracle.scan_batch(poses, return_lookups=True)
+    out, lk = eng.scan(poses, want_lookups=True)
+    assert np.array_equal(_np(out), ref) and np.array_equal(_np(lk).astype(np.int64), rlk)
