@@ -193,6 +193,42 @@ int f110_check_ttc(f110_handle *h, const double *scans, const double *vel, int32
 int f110_ray_cast(f110_handle *h, const double *ego_poses, const double *opp_verts, int32_t n,
                   double *scans, int32_t *span, void *stream);
 
+/* ---- scan -> bird's-eye bitmap (the first consumer of the step's scans) ----
+ * Replaces weap_util/weap_util/lidar.py:105-154 `lidar_to_bitmap` (same body in src/SAL.py:274-395
+ * and src/bitmap.py:4-140), which draws one scan with OpenCV 4.11 (fillPoly / polylines / line /
+ * rectangle, 8-bit, LINE_8).  A renderer holds the scan-independent tables the reference rebuilds
+ * per call (lidar.py:63-72): indices = np.linspace(0, num_beams-1, T, dtype=int) and cos / sin of
+ * angles = starting_angle + dir*fov*np.linspace(0, 1, T) -- computed by the caller with numpy so that
+ * they are the reference's own values (host pointers, copied). */
+#define F110_BITMAP_FILL 0
+#define F110_BITMAP_POLYGON 1
+#define F110_BITMAP_RAYS 2
+typedef struct f110_bitmap f110_bitmap;
+typedef struct {
+    int32_t device;
+    int32_t num_beams;          /* len(scan) */
+    int32_t target_beam_count;  /* T, 0 < T < num_beams, T <= 2048 */
+    int32_t rows, cols;         /* output_image_dims */
+    int32_t channels;           /* 1, 3 or 4 (alpha = 255) */
+    int32_t draw_mode;          /* F110_BITMAP_* */
+    int32_t bg_value, draw_value; /* grey levels (0/255 white-on-black etc., lidar.py:61; 0/180 in src/bitmap.py:60) */
+    int32_t draw_center;
+    double scaling_factor;      /* pixels per metre (min(dims)/max_scan_radius when that is given) */
+} f110_bitmap_config;
+int f110_bitmap_create(const f110_bitmap_config *cfg, const int32_t *indices, const double *cosines,
+                       const double *sines, f110_bitmap **out);
+void f110_bitmap_destroy(f110_bitmap *b);
+/* n scans (dev, f32 or f64, `stride` elements apart) -> out dev uint8 [n, rows, cols(, channels)].
+ * Enqueued on `stream`; no allocation, no synchronisation. */
+int f110_bitmap_render(f110_bitmap *b, const void *scans, int32_t scans_f64, int64_t n, int64_t stride,
+                       uint8_t *out, void *stream);
+/* Point-occupancy grid of f1tenth_gym/examples/lidar.py:212-244 (the routine that wrote the
+ * reference's lidar_datasets): out dev uint8 [n, grid, grid] of 0/1.  cosines / sines: dev [num_beams],
+ * of np.linspace(-135, 135, num_beams) * pi / 180. */
+int f110_scan_occupancy(const void *scans, int32_t scans_f64, int64_t n, int64_t stride, int32_t num_beams,
+                        const double *cosines, const double *sines, double max_range, double lo, double hi,
+                        int32_t grid, uint8_t *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,4 +14,7 @@ def __getattr__(name):
     if name == 'F110Env':
         from .f110_env import F110Env
         return F110Env
+    if name in ('lidar_to_bitmap', 'LidarBitmap', 'scan_occupancy'):
+        from . import lidar
+        return getattr(lidar, name)
     raise AttributeError(name)

@@ -31,6 +31,13 @@ BUFFER_FIELDS = ['state', 'steer_buf', 'steer_cnt', 'noise_step', 'spawn', 'star
                  'collisions', 'collision_idx', 'in_collision', 'lap_counts', 'lap_times', 'done', 'checkpoint_done', 'lookups']
 
 
+class BitmapConfig(C.Structure):
+    _fields_ = [('device', C.c_int32), ('num_beams', C.c_int32), ('target_beam_count', C.c_int32),
+                ('rows', C.c_int32), ('cols', C.c_int32), ('channels', C.c_int32), ('draw_mode', C.c_int32),
+                ('bg_value', C.c_int32), ('draw_value', C.c_int32), ('draw_center', C.c_int32),
+                ('scaling_factor', C.c_double)]
+
+
 class Buffers(C.Structure):
     _fields_ = [(name, C.c_void_p) for name in BUFFER_FIELDS]
 
@@ -62,6 +69,10 @@ SYMBOLS = {
     'f110_collision_multiple': [_VP, _VP, _I32, _I32, _VP, _VP, _VP],
     'f110_check_ttc': [_VP, _VP, _VP, _I32, _VP, _VP],
     'f110_ray_cast': [_VP, _VP, _VP, _I32, _VP, _VP, _VP],
+    'f110_bitmap_create': [C.POINTER(BitmapConfig), _VP, _VP, _VP, C.POINTER(_VP)],
+    'f110_bitmap_destroy': [_VP],
+    'f110_bitmap_render': [_VP, _VP, _I32, _I64, _I64, _VP, _VP],
+    'f110_scan_occupancy': [_VP, _I32, _I64, _I64, _I32, _VP, _VP, _D, _D, _D, _I32, _VP, _VP],
 }
 
 
@@ -94,6 +105,7 @@ def load():
         fn.restype = C.c_int
     lib.f110_last_error.restype = C.c_char_p
     lib.f110_destroy.restype = None
+    lib.f110_bitmap_destroy.restype = None
     _lib = lib
     return lib
 

@@ -5,6 +5,7 @@
 #include "../../include/f110_hip.h"
 #include "f110_kernels.h"
 #include "f110_planner.h"
+#include "f110_bitmap.h"
 
 #include <algorithm>
 #include <cmath>
@@ -774,6 +775,98 @@ extern "C" int f110_ray_cast(f110_handle *h, const double *ego, const double *ve
     if (!h || !ego || !verts || !scans || n < 0) return fail(F110_E_INVALID, "f110_ray_cast: bad arguments");
     hipLaunchKernelGGL(ray_cast_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, ego, verts, n,
                        h->cfg.num_beams, h->d_scan_angles, h->d_beam_cs, scans, span);
+    HIP_TRY(hipGetLastError());
+    return F110_OK;
+}
+
+// ---------------------------------------------------------------- scan -> bitmap
+struct f110_bitmap {
+    f110_bitmap_config cfg;
+    int32_t *d_idx = nullptr;
+    double *d_cos = nullptr, *d_sin = nullptr;
+    int S = 0;
+    size_t lds = 0;
+};
+
+extern "C" void f110_bitmap_destroy(f110_bitmap *b)
+{
+    if (!b) return;
+    (void)hipSetDevice(b->cfg.device);
+    if (b->d_idx) (void)hipFree(b->d_idx);
+    if (b->d_cos) (void)hipFree(b->d_cos);
+    if (b->d_sin) (void)hipFree(b->d_sin);
+    delete b;
+}
+
+extern "C" int f110_bitmap_create(const f110_bitmap_config *cfg, const int32_t *indices, const double *cosines,
+                                  const double *sines, f110_bitmap **out)
+{
+    if (!cfg || !indices || !cosines || !sines || !out) return fail(F110_E_INVALID, "f110_bitmap_create: null argument");
+    const int T = cfg->target_beam_count;
+    // the reference's assertions (lidar.py:50-56)
+    if (!(T > 0 && T < cfg->num_beams)) return fail(F110_E_INVALID, "target_beam_count must satisfy 0 < %d < len(scan) = %d", T, cfg->num_beams);
+    if (T > 2048) return fail(F110_E_INVALID, "target_beam_count %d > 2048", T);
+    if (cfg->rows <= 0 || cfg->cols <= 0) return fail(F110_E_INVALID, "output_image_dims must be at least 1x1");
+    if (cfg->rows > 4096 || cfg->cols > 4096) return fail(F110_E_INVALID, "output_image_dims above 4096 are not supported");
+    if (cfg->channels != 1 && cfg->channels != 3 && cfg->channels != 4) return fail(F110_E_INVALID, "channels must 1, 3, or 4");
+    if (cfg->draw_mode < F110_BITMAP_FILL || cfg->draw_mode > F110_BITMAP_RAYS) return fail(F110_E_INVALID, "draw_mode must be FILL, POLYGON or RAYS");
+    for (int k = 0; k < T; k++)
+        if (indices[k] < 0 || indices[k] >= cfg->num_beams) return fail(F110_E_INDEX, "beam index %d out of range", indices[k]);
+    int S = (cfg->cols + 31) / 32;
+    S |= 1; // odd row pitch: the per-row parity pass is LDS-bank-conflict free
+    const size_t lds = bitmap_lds_bytes(T, cfg->rows, S);
+    if (lds > 150 * 1024) return fail(F110_E_INVALID, "image %dx%d with %d beams needs %zu bytes of LDS (limit 150 KiB)", cfg->rows, cfg->cols, T, lds);
+    f110_bitmap *b = new (std::nothrow) f110_bitmap;
+    if (!b) return fail(F110_E_INVALID, "out of memory");
+    b->cfg = *cfg; b->S = S; b->lds = lds;
+    if (hipSetDevice(cfg->device) != hipSuccess) { delete b; return fail(F110_E_HIP, "hipSetDevice(%d) failed", cfg->device); }
+    hipError_t e = hipMalloc((void **)&b->d_idx, T * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&b->d_cos, T * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void **)&b->d_sin, T * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpy(b->d_idx, indices, T * sizeof(int32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(b->d_cos, cosines, T * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(b->d_sin, sines, T * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess && lds > 64 * 1024)
+        e = hipFuncSetAttribute((const void *)bitmap_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { f110_bitmap_destroy(b); return fail(F110_E_HIP, "f110_bitmap_create: %s", hipGetErrorString(e)); }
+    *out = b;
+    return F110_OK;
+}
+
+extern "C" int f110_bitmap_render(f110_bitmap *b, const void *scans, int32_t scans_f64, int64_t n, int64_t stride,
+                                  uint8_t *out, void *stream)
+{
+    if (!b || n < 0) return fail(F110_E_INVALID, "f110_bitmap_render: bad arguments");
+    if (n == 0) return F110_OK;
+    if (!scans || !out) return fail(F110_E_INVALID, "f110_bitmap_render: null pointer");
+    if (stride < b->cfg.num_beams || n > 0x7fffffff) return fail(F110_E_INVALID, "f110_bitmap_render: stride %lld < num_beams or n too large", (long long)stride);
+    if ((uintptr_t)out % 16) return fail(F110_E_INVALID, "f110_bitmap_render: out must be 16-byte aligned");
+    BitmapArgs a;
+    a.scans = scans; a.is_f64 = scans_f64 != 0; a.stride = stride; a.n = (int)n;
+    a.idx = b->d_idx; a.cosv = b->d_cos; a.sinv = b->d_sin; a.T = b->cfg.target_beam_count;
+    a.rows = b->cfg.rows; a.cols = b->cfg.cols; a.channels = b->cfg.channels; a.mode = b->cfg.draw_mode;
+    a.bg = b->cfg.bg_value; a.draw = b->cfg.draw_value; a.draw_center = b->cfg.draw_center;
+    a.scale = b->cfg.scaling_factor; a.out = out; a.S = b->S;
+    hipLaunchKernelGGL(bitmap_kernel, dim3((unsigned)n), dim3(BM_THREADS), b->lds, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return F110_OK;
+}
+
+extern "C" int f110_scan_occupancy(const void *scans, int32_t scans_f64, int64_t n, int64_t stride, int32_t num_beams,
+                                   const double *cosines, const double *sines, double max_range, double lo, double hi,
+                                   int32_t grid, uint8_t *out, void *stream)
+{
+    if (n < 0 || num_beams <= 0 || grid <= 0 || grid > 1024) return fail(F110_E_INVALID, "f110_scan_occupancy: bad arguments");
+    if (n == 0) return F110_OK;
+    if (!scans || !cosines || !sines || !out) return fail(F110_E_INVALID, "f110_scan_occupancy: null pointer");
+    if (stride < num_beams || n > 0x7fffffff) return fail(F110_E_INVALID, "f110_scan_occupancy: stride < num_beams or n too large");
+    OccArgs a;
+    a.scans = scans; a.is_f64 = scans_f64 != 0; a.stride = stride; a.n = (int)n; a.num_beams = num_beams;
+    a.cosv = cosines; a.sinv = sines; a.max_range = max_range; a.lo = lo; a.hi = hi; a.grid = grid; a.out = out;
+    const size_t lds = (size_t)((grid * grid + 31) / 32) * 4;
+    if (lds > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void *)occupancy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(occupancy_kernel, dim3((unsigned)n), dim3(BM_THREADS), lds, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return F110_OK;
 }
