@@ -860,6 +860,7 @@ extern "C" int f110_scan_occupancy(const void *scans, int32_t scans_f64, int64_t
     if (n == 0) return F110_OK;
     if (!scans || !cosines || !sines || !out) return fail(F110_E_INVALID, "f110_scan_occupancy: null pointer");
     if (stride < num_beams || n > 0x7fffffff) return fail(F110_E_INVALID, "f110_scan_occupancy: stride < num_beams or n too large");
+    if ((uintptr_t)out % 16) return fail(F110_E_INVALID, "f110_scan_occupancy: out must be 16-byte aligned");
     OccArgs a;
     a.scans = scans; a.is_f64 = scans_f64 != 0; a.stride = stride; a.n = (int)n; a.num_beams = num_beams;
     a.cosv = cosines; a.sinv = sines; a.max_range = max_range; a.lo = lo; a.hi = hi; a.grid = grid; a.out = out;

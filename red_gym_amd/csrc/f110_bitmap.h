@@ -19,7 +19,12 @@
 namespace f110 {
 
 enum { BM_FILL = 0, BM_POLYGON = 1, BM_RAYS = 2 };
-constexpr int BM_THREADS = 256;
+#ifndef F110_BM_THREADS
+#define F110_BM_THREADS 512
+#endif
+constexpr int BM_THREADS = F110_BM_THREADS;
+constexpr int BM_MAX_T = 2048;
+constexpr int BM_PER_MAX = (BM_MAX_T + BM_THREADS - 1) / BM_THREADS;
 constexpr int BM_XY_SHIFT = 16;
 
 struct BitmapArgs {
@@ -36,19 +41,22 @@ struct BitmapArgs {
     int S;                   // words per bit-plane row (cols/32 rounded up, made odd)
 };
 
-struct LineRec { int x0, y0, dmaj, dmin; int sy, vert; };
-struct EdgeRec { long long x, dx; int y0, ya; };
+// One segment / polygon edge, ready to be walked item by item (32 bytes, two ds_read_b128):
+//   items [0, L)      Bresenham pixels of the (clipped) segment, L = dmaj + 1 or 0
+//   items [L, L + R)  FILL: crossings of the edge with image rows ya .. ya + R - 1, x in 48.16 fixed point
+//                     RAYS: the 25 pixels of the 5x5 marker around the segment's end point
+struct alignas(16) EdgeRec {
+    unsigned xy0;        // x0 | y0 << 16: first pixel of the walk (inside the image)
+    unsigned lin;        // dmaj | dmin << 13 | (sy < 0) << 26 | vert << 27 | has_line << 28
+    unsigned rows;       // ya | R << 16
+    int mark;            // RAYS: marker centre x | y << 16 (as int16)
+    long long x, dx;     // crossing at row ya and its per-row increment
+};
 
 __host__ __device__ inline size_t bitmap_lds_bytes(int T, int rows, int S)
 {
-    // pts int2[T] | start int[T+1] | LineRec[T] | EdgeRec[T] | any[rows*S] | par[rows*S] | carry[rows]
-    size_t b = (size_t)T * 8 + (size_t)(T + 1) * 4;
-    b = (b + 7) & ~(size_t)7;
-    b += (size_t)T * sizeof(LineRec);
-    b = (b + 7) & ~(size_t)7;
-    b += (size_t)T * sizeof(EdgeRec);
-    b += (size_t)rows * S * 4 * 2 + (size_t)rows * 4;
-    return b;
+    // EdgeRec[T] | pts int2[T] | start int[T+1] | any[rows*S] | par[rows*S] | carry[rows]
+    return (size_t)T * sizeof(EdgeRec) + (size_t)T * 8 + (size_t)(T + 1) * 4 + (size_t)rows * S * 4 * 2 + (size_t)rows * 4;
 }
 
 // cv::clipLine(Size2l, Point2l&, Point2l&), drawing.cpp
@@ -89,36 +97,65 @@ __device__ inline bool bm_clip_line(long long width, long long height, long long
     return (c1 | c2) == 0;
 }
 
-// Line() + LineIterator::init (connectivity 8, leftToRight): the record of one segment; returns its pixel count
-__device__ inline int bm_line_setup(int rows, int cols, int ax, int ay, int bx, int by, LineRec &r)
+// Line() + LineIterator::init (connectivity 8, leftToRight) and, for FILL, CollectPolyEdges (LINE_8, shift 0)
+// of the segment p0 -> p1.  Both clip the same end points with clipLine, so it runs once.  Returns the item count.
+__device__ inline int bm_edge_setup(int mode, int rows, int cols, int2 p0, int2 p1, EdgeRec &r)
 {
-    long long x1 = ax, y1 = ay, x2 = bx, y2 = by;
-    if ((unsigned long long)x1 >= (unsigned long long)cols || (unsigned long long)x2 >= (unsigned long long)cols ||
-        (unsigned long long)y1 >= (unsigned long long)rows || (unsigned long long)y2 >= (unsigned long long)rows) {
-        if (!bm_clip_line(cols, rows, x1, y1, x2, y2)) { r.dmaj = -1; return 0; }
+    long long tx0 = p0.x, ty0 = p0.y, tx1 = p1.x, ty1 = p1.y;
+    const bool outside = (unsigned)p0.x >= (unsigned)cols || (unsigned)p1.x >= (unsigned)cols ||
+                         (unsigned)p0.y >= (unsigned)rows || (unsigned)p1.y >= (unsigned)rows;
+    bool visible = true;
+    if (outside) visible = bm_clip_line(cols, rows, tx0, ty0, tx1, ty1);
+    int L = 0;
+    r.xy0 = 0; r.lin = 0; r.rows = 0; r.mark = 0; r.x = 0; r.dx = 0;
+    if (visible) {
+        long long x1 = tx0, y1 = ty0;
+        int dx = (int)(tx1 - tx0), dy = (int)(ty1 - ty0);
+        if (dx < 0) { dx = -dx; dy = -dy; x1 = tx1; y1 = ty1; }      // leftToRight
+        unsigned neg = 0;
+        if (dy < 0) { dy = -dy; neg = 1; }
+        const unsigned vert = dy > dx;
+        const unsigned dmaj = vert ? dy : dx, dmin = vert ? dx : dy;
+        r.xy0 = (unsigned)x1 | (unsigned)y1 << 16;
+        r.lin = dmaj | dmin << 13 | neg << 26 | vert << 27 | 1u << 28;
+        L = (int)dmaj + 1;
     }
-    int dx = (int)(x2 - x1), dy = (int)(y2 - y1);
-    if (dx < 0) { dx = -dx; dy = -dy; x1 = x2; y1 = y2; }
-    int sy = 1;
-    if (dy < 0) { dy = -dy; sy = -1; }
-    const int vert = dy > dx;
-    r.x0 = (int)x1; r.y0 = (int)y1; r.sy = sy; r.vert = vert;
-    r.dmaj = vert ? dy : dx;
-    r.dmin = vert ? dx : dy;
-    return r.dmaj + 1;
+    int R = 0;
+    if (mode == BM_FILL && p0.y != p1.y) {
+        const long long half = 1ll << (BM_XY_SHIFT - 1);
+        long long c0x = (long long)p0.x << BM_XY_SHIFT, c1x = (long long)p1.x << BM_XY_SHIFT, c0y = p0.y, c1y = p1.y;
+        if (outside) {   // "use clipped endpoints to create a more accurate PolyEdge"
+            if (ty0 != ty1) { c0y = ty0; c1y = ty1; c0x = tx0 << BM_XY_SHIFT; c1x = tx1 << BM_XY_SHIFT; }
+        } else {
+            c0x += half; c1x += half;
+        }
+        // int64 quotient truncated toward zero; |numerator| < 2^49, so the rounded fp64 quotient truncates to the same integer
+        const long long dx = (long long)((double)(c1x - c0x) / (double)(c1y - c0y));
+        int y0, y1;
+        long long x;
+        if (p0.y < p1.y) { y0 = p0.y; y1 = p1.y; x = c0x + ((long long)p0.y - c0y) * dx; }
+        else { y0 = p1.y; y1 = p0.y; x = c1x + ((long long)p1.y - c1y) * dx; }
+        const int ya = y0 > 0 ? y0 : 0, yb = y1 < rows ? y1 : rows;
+        if (yb > ya) {
+            R = yb - ya;
+            r.rows = (unsigned)ya | (unsigned)R << 16;
+            r.x = x + (long long)(ya - y0) * dx;
+            r.dx = dx;
+        }
+    } else if (mode == BM_RAYS) {
+        // lidar.py:95: cv2.rectangle(p - 2, p + 2, filled); markers wholly outside the image draw nothing
+        if (p1.x >= -2 && p1.x < cols + 2 && p1.y >= -2 && p1.y < rows + 2) {
+            R = 25;
+            r.mark = (int)((unsigned)(p1.x & 0xffff) | (unsigned)p1.y << 16);
+        }
+    }
+    return L + R;
 }
 
 __device__ inline void bm_set(unsigned *plane, int S, int x, int y) { atomicOr(&plane[y * S + (x >> 5)], 1u << (x & 31)); }
 
-__device__ inline void bm_line_pixel(const LineRec &r, int k, int &x, int &y)
-{
-    const int m = r.dmaj > 0 ? (2 * r.dmin * k + r.dmaj - 1) / (2 * r.dmaj) : 0;
-    if (r.vert) { x = r.x0 + m; y = r.y0 + r.sy * k; }
-    else { x = r.x0 + k; y = r.y0 + r.sy * m; }
-}
-
-// block-wide exclusive scan of one int per thread (BM_THREADS threads); returns the exclusive prefix, total in `total`
-__device__ inline int bm_block_scan(int v, int &total, int *s_wave /*[4]*/)
+// block-wide exclusive scan of one int per thread; returns the exclusive prefix, the sum in `total`
+__device__ inline int bm_block_scan(int v, int &total, int *s_wave)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int incl = v;
@@ -126,7 +163,6 @@ __device__ inline int bm_block_scan(int v, int &total, int *s_wave /*[4]*/)
         const int t = __shfl_up(incl, off, 64);
         if (lane >= off) incl += t;
     }
-    __syncthreads();
     if (lane == 63) s_wave[wave] = incl;
     __syncthreads();
     int base = 0, tot = 0;
@@ -137,32 +173,6 @@ __device__ inline int bm_block_scan(int v, int &total, int *s_wave /*[4]*/)
     }
     total = tot;
     return base + incl - v;
-}
-
-// CollectPolyEdges (LINE_8, shift 0): the fill record of the edge pt0 -> pt1; returns the number of image rows it crosses
-__device__ inline int bm_edge_setup(int rows, int cols, int p0x, int p0y, int p1x, int p1y, EdgeRec &e)
-{
-    e.ya = 0; e.y0 = 0; e.x = 0; e.dx = 0;
-    if (p0y == p1y) return 0;
-    const long long half = 1ll << (BM_XY_SHIFT - 1);
-    long long c0x = (long long)p0x << BM_XY_SHIFT, c1x = (long long)p1x << BM_XY_SHIFT, c0y = p0y, c1y = p1y;
-    if ((unsigned)p0x >= (unsigned)cols || (unsigned)p1x >= (unsigned)cols || (unsigned)p0y >= (unsigned)rows ||
-        (unsigned)p1y >= (unsigned)rows) {
-        long long tx0 = p0x, ty0 = p0y, tx1 = p1x, ty1 = p1y;
-        bm_clip_line(cols, rows, tx0, ty0, tx1, ty1);
-        if (ty0 != ty1) { c0y = ty0; c1y = ty1; c0x = tx0 << BM_XY_SHIFT; c1x = tx1 << BM_XY_SHIFT; }
-    } else {
-        c0x += half; c1x += half;
-    }
-    const long long dx = (c1x - c0x) / (c1y - c0y);
-    int y0, y1;
-    long long x;
-    if (p0y < p1y) { y0 = p0y; y1 = p1y; x = c0x + ((long long)p0y - c0y) * dx; }
-    else { y0 = p1y; y1 = p0y; x = c1x + ((long long)p1y - c1y) * dx; }
-    e.x = x; e.dx = dx; e.y0 = y0;
-    const int ya = y0 > 0 ? y0 : 0, yb = y1 < rows ? y1 : rows;
-    e.ya = ya;
-    return yb > ya ? yb - ya : 0;
 }
 
 // first index e in [0, n) with start[e + 1] > j  (start is an exclusive prefix with start[n] = total)
@@ -176,26 +186,26 @@ __device__ inline int bm_find(const int *start, int n, int j)
     return lo;
 }
 
-__device__ inline unsigned bm_bit(const unsigned *plane, int S, int x, int y) { return (plane[y * S + (x >> 5)] >> (x & 31)) & 1u; }
+// 4 pixel bits -> 4 bytes, each bg (bit 0) or draw (bit 1); cols = bg | draw << 8
+__device__ inline unsigned bm_expand4(unsigned nib, unsigned cols2)
+{
+    const unsigned sel = (nib * 0x00204081u) & 0x01010101u; // bit i -> byte i (0 or 1): a v_perm selector
+    return __builtin_amdgcn_perm(0u, cols2, sel);
+}
 
 __global__ __launch_bounds__(BM_THREADS) void bitmap_kernel(BitmapArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     __shared__ int s_wave[BM_THREADS / 64];
-    const int T = a.T, rows = a.rows, cols = a.cols, S = a.S, tid = threadIdx.x;
-    int2 *pts = reinterpret_cast<int2 *>(s_raw);
-    int *start = reinterpret_cast<int *>(s_raw + (size_t)T * 8);
-    size_t off = ((size_t)T * 8 + (size_t)(T + 1) * 4 + 7) & ~(size_t)7;
-    LineRec *lines = reinterpret_cast<LineRec *>(s_raw + off);
-    off = (off + (size_t)T * sizeof(LineRec) + 7) & ~(size_t)7;
-    EdgeRec *edges = reinterpret_cast<EdgeRec *>(s_raw + off);
-    off += (size_t)T * sizeof(EdgeRec);
-    unsigned *anyp = reinterpret_cast<unsigned *>(s_raw + off);
+    const int T = a.T, rows = a.rows, cols = a.cols, S = a.S, tid = threadIdx.x, mode = a.mode;
+    EdgeRec *recs = reinterpret_cast<EdgeRec *>(s_raw);
+    int2 *pts = reinterpret_cast<int2 *>(s_raw + (size_t)T * sizeof(EdgeRec));
+    int *start = reinterpret_cast<int *>(pts + T);
+    unsigned *anyp = reinterpret_cast<unsigned *>(start + T + 1);
     unsigned *parp = anyp + rows * S;
     unsigned *carry = parp + rows * S;
 
     const int img = blockIdx.x;
-    if (img >= a.n) return;
     const int cx = rows / 2, cy = cols / 2; // lidar.py:75: center = (dims[0]//2, dims[1]//2), used as (x, y)
 
     for (int i = tid; i < rows * S * 2 + rows; i += BM_THREADS) anyp[i] = 0u;
@@ -209,148 +219,152 @@ __global__ __launch_bounds__(BM_THREADS) void bitmap_kernel(BitmapArgs a)
     }
     __syncthreads();
 
-    // ---- segments: polygon outline (FILL, POLYGON) or centre -> point rays (RAYS)
+    // ---- one record per segment: polygon edges pts[i-1] -> pts[i] (FILL, POLYGON) or rays centre -> pts[i]
     const int per = (T + BM_THREADS - 1) / BM_THREADS;
-    {
-        int cnt[8], local = 0;
-        for (int q = 0; q < per; q++) {
-            const int i = tid * per + q;
-            cnt[q & 7] = 0;
-            if (i < T) {
-                const int2 p1 = pts[i];
-                const int2 p0 = a.mode == BM_RAYS ? make_int2(cx, cy) : pts[i == 0 ? T - 1 : i - 1];
-                LineRec r;
-                cnt[q & 7] = bm_line_setup(rows, cols, p0.x, p0.y, p1.x, p1.y, r);
-                lines[i] = r;
-            }
-            local += cnt[q & 7];
+    int cnt[BM_PER_MAX], local = 0;
+#pragma unroll
+    for (int q = 0; q < BM_PER_MAX; q++) {
+        cnt[q] = 0;
+        const int i = tid * per + q;
+        if (q < per && i < T) {
+            const int2 p1 = pts[i];
+            const int2 p0 = mode == BM_RAYS ? make_int2(cx, cy) : pts[i == 0 ? T - 1 : i - 1];
+            EdgeRec r;
+            cnt[q] = bm_edge_setup(mode, rows, cols, p0, p1, r);
+            recs[i] = r;
         }
-        int total;
-        int base = bm_block_scan(local, total, s_wave);
-        for (int q = 0; q < per; q++) {
-            const int i = tid * per + q;
-            if (i < T) { start[i] = base; base += cnt[q & 7]; }
-        }
-        if (tid == 0) start[T] = total;
-        __syncthreads();
-        const int ipt = (total + BM_THREADS - 1) / BM_THREADS;
-        int j = tid * ipt;
-        const int jend = min(j + ipt, total);
-        if (j < jend) {
-            int e = bm_find(start, T, j);
-            for (; j < jend; j++) {
-                while (start[e + 1] <= j) e++;
-                int x, y;
-                bm_line_pixel(lines[e], j - start[e], x, y);
-                bm_set(anyp, S, x, y);
-            }
-        }
-        __syncthreads();
+        local += cnt[q];
     }
+    int total;
+    int base = bm_block_scan(local, total, s_wave);
+#pragma unroll
+    for (int q = 0; q < BM_PER_MAX; q++) {
+        const int i = tid * per + q;
+        if (q < per && i < T) { start[i] = base; base += cnt[q]; }
+    }
+    if (tid == 0) start[T] = total;
+    if (a.draw_center && mode != BM_FILL && tid < 25) {
+        // lidar.py:98-100: centre marker in the draw colour (FILL clears it after the fill, below)
+        const int x = cx - 2 + tid % 5, y = cy - 2 + tid / 5;
+        if ((unsigned)x < (unsigned)cols && (unsigned)y < (unsigned)rows) bm_set(anyp, S, x, y);
+    }
+    __syncthreads();
 
-    if (a.mode == BM_FILL) {
-        // ---- crossings of every non-horizontal edge with every image row it spans
-        int cnt[8], local = 0;
-        for (int q = 0; q < per; q++) {
-            const int i = tid * per + q;
-            cnt[q & 7] = 0;
-            if (i < T) {
-                const int2 p1 = pts[i], p0 = pts[i == 0 ? T - 1 : i - 1];
-                EdgeRec e;
-                cnt[q & 7] = bm_edge_setup(rows, cols, p0.x, p0.y, p1.x, p1.y, e);
-                edges[i] = e;
-            }
-            local += cnt[q & 7];
-        }
-        int total;
-        int base = bm_block_scan(local, total, s_wave);
-        for (int q = 0; q < per; q++) {
-            const int i = tid * per + q;
-            if (i < T) { start[i] = base; base += cnt[q & 7]; }
-        }
-        if (tid == 0) start[T] = total;
-        __syncthreads();
+    // ---- walk the items: every thread takes a contiguous share of all segments' pixels / crossings / marker pixels
+    {
         const int ipt = (total + BM_THREADS - 1) / BM_THREADS;
         int j = tid * ipt;
         const int jend = min(j + ipt, total);
         if (j < jend) {
             int e = bm_find(start, T, j);
-            for (; j < jend; j++) {
-                while (start[e + 1] <= j) e++;
-                const EdgeRec ed = edges[e];
-                const int y = ed.ya + (j - start[e]);
-                const long long X = (ed.x + (long long)(y - ed.y0) * ed.dx) >> BM_XY_SHIFT;
-                if (X < 0) atomicXor(&carry[y], 1u);
-                else if (X < cols) {
-                    atomicXor(&parp[y * S + (int)(X >> 5)], 1u << (X & 31));
-                    bm_set(anyp, S, (int)X, y);
+            int k = j - start[e], n_items = start[e + 1] - start[e];
+            EdgeRec r = recs[e];
+            int L = (r.lin >> 28) ? (int)(r.lin & 0x1fffu) + 1 : 0;
+            // Bresenham state after k major steps: minor offset m, error term err (LineIterator's recurrence in closed form)
+            int dmaj = (int)(r.lin & 0x1fffu), dmin = (int)((r.lin >> 13) & 0x1fffu);
+            int m = (k > 0 && k < L) ? (2 * dmin * k + dmaj - 1) / (2 * dmaj) : 0;
+            int err = dmaj - 2 * dmin * (k + 1) + 2 * dmaj * m;
+            long long xr = r.x + (long long)(k > L ? k - L : 0) * r.dx;
+            for (; j < jend; j++, k++) {
+                while (k >= n_items) {   // next segment with at least one item
+                    e++;
+                    n_items = start[e + 1] - start[e];
+                    k = 0;
+                    if (n_items > 0) {
+                        r = recs[e];
+                        L = (r.lin >> 28) ? (int)(r.lin & 0x1fffu) + 1 : 0;
+                        dmaj = (int)(r.lin & 0x1fffu); dmin = (int)((r.lin >> 13) & 0x1fffu);
+                        m = 0; err = dmaj - 2 * dmin;
+                        xr = r.x;
+                    }
+                }
+                if (k < L) {
+                    const int x0 = (int)(r.xy0 & 0xffffu), y0 = (int)(r.xy0 >> 16);
+                    const int sy = (r.lin >> 26) & 1u ? -1 : 1;
+                    const bool vert = (r.lin >> 27) & 1u;
+                    const int x = vert ? x0 + m : x0 + k, y = vert ? y0 + sy * k : y0 + sy * m;
+                    bm_set(anyp, S, x, y);
+                    const int neg = err < 0;
+                    err += (neg ? 2 * dmaj : 0) - 2 * dmin;
+                    m += neg;
+                } else if (mode == BM_FILL) {
+                    const int y = (int)(r.rows & 0xffffu) + (k - L);
+                    const long long X = xr >> BM_XY_SHIFT;
+                    xr += r.dx;
+                    if (X < 0) atomicXor(&carry[y], 1u);
+                    else if (X < cols) {
+                        atomicXor(&parp[y * S + (int)(X >> 5)], 1u << (X & 31));
+                        bm_set(anyp, S, (int)X, y);
+                    }
+                } else {
+                    const int q = k - L;
+                    const int x = (int)(short)(r.mark & 0xffff) - 2 + q % 5, y = (r.mark >> 16) - 2 + q / 5;
+                    if ((unsigned)x < (unsigned)cols && (unsigned)y < (unsigned)rows) bm_set(anyp, S, x, y);
                 }
             }
-        }
-        __syncthreads();
-        // ---- inside = crossing on the pixel, or odd number of crossings strictly left of it
-        for (int y = tid; y < rows; y += BM_THREADS) {
-            unsigned c = carry[y] & 1u;
-            for (int w = 0; w < S; w++) {
-                unsigned p = parp[y * S + w];
-                p ^= p << 1; p ^= p << 2; p ^= p << 4; p ^= p << 8; p ^= p << 16; // inclusive prefix parity
-                const unsigned inside = (p << 1) ^ (0u - c);
-                c ^= p >> 31;
-                anyp[y * S + w] |= inside;
-            }
-        }
-        __syncthreads();
-    }
-
-    if (a.mode == BM_RAYS) {
-        // lidar.py:95: cv2.rectangle(p - 2, p + 2, filled) around every point
-        for (int i = tid; i < T * 25; i += BM_THREADS) {
-            const int2 p = pts[i / 25];
-            const int x = p.x - 2 + (i % 25) % 5, y = p.y - 2 + (i % 25) / 5;
-            if ((unsigned)x < (unsigned)cols && (unsigned)y < (unsigned)rows) bm_set(anyp, S, x, y);
-        }
-        __syncthreads();
-    }
-    if (a.draw_center && tid < 25) {
-        // lidar.py:98-100: the centre marker, background colour in FILL mode
-        const int x = cx - 2 + tid % 5, y = cy - 2 + tid / 5;
-        if ((unsigned)x < (unsigned)cols && (unsigned)y < (unsigned)rows) {
-            if (a.mode == BM_FILL) atomicAnd(&anyp[y * S + (x >> 5)], ~(1u << (x & 31)));
-            else bm_set(anyp, S, x, y);
         }
     }
     __syncthreads();
 
-    // ---- stream the image out: grey levels and channels are expanded here
+    if (mode == BM_FILL) {
+        // ---- inside = crossing on the pixel, or an odd number of crossings strictly left of it; then the centre marker
+        for (int y = tid; y < rows; y += BM_THREADS) {
+            unsigned c = carry[y] & 1u;
+            const bool marker_row = a.draw_center && y >= cy - 2 && y <= cy + 2;
+            for (int w = 0; w < S; w++) {
+                unsigned p = parp[y * S + w];
+                p ^= p << 1; p ^= p << 2; p ^= p << 4; p ^= p << 8; p ^= p << 16; // inclusive prefix parity
+                unsigned v = anyp[y * S + w] | ((p << 1) ^ (0u - c));
+                c ^= p >> 31;
+                if (marker_row) {   // lidar.py:98-100: 5x5 box in the background colour
+                    const int lo = max(cx - 2, 32 * w), hi = min(cx + 2, 32 * w + 31);
+                    if (lo <= hi) v &= ~((0xffffffffu >> (31 - (hi - lo))) << (lo - 32 * w));
+                }
+                anyp[y * S + w] = v;
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- stream the image out: grey levels and channels are expanded here (the only HBM write)
     const int ch = a.channels;
     const size_t img_bytes = (size_t)rows * cols * ch;
     unsigned char *dst = a.out + (size_t)img * img_bytes;
-    const unsigned bg = (unsigned)a.bg & 255u, flip = ((unsigned)a.bg ^ (unsigned)a.draw) & 255u;
-    if (ch == 1 && (cols & 31) == 0) {
-        // 16 pixels (half a plane word) -> one 16-byte store
+    const unsigned cols2 = ((unsigned)a.bg & 255u) | ((unsigned)a.draw & 255u) << 8;
+    if ((cols & 15) == 0) {
+        // 16 pixels (half a plane word) per step: 16 / 48 / 64 output bytes as 16-byte stores
         const int chunks = rows * cols / 16, cpr = cols / 16;
+        uint4 *dst4 = reinterpret_cast<uint4 *>(dst);
         for (int c = tid; c < chunks; c += BM_THREADS) {
             const int y = c / cpr, h = c - y * cpr;
             const unsigned bits = (anyp[y * S + (h >> 1)] >> ((h & 1) * 16)) & 0xffffu;
-            uint4 v;
-            unsigned *vw = reinterpret_cast<unsigned *>(&v);
-            for (int q = 0; q < 4; q++) {
-                const unsigned nib = (bits >> (4 * q)) & 15u;
-                const unsigned ones = ((nib * 0x00204081u) & 0x01010101u) * 255u; // bit i -> byte i = 0xff
-                vw[q] = (bg * 0x01010101u) ^ (ones & (flip * 0x01010101u));
+            unsigned e4[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) e4[q] = bm_expand4((bits >> (4 * q)) & 15u, cols2);
+            if (ch == 1) {
+                dst4[c] = make_uint4(e4[0], e4[1], e4[2], e4[3]);
+            } else if (ch == 3) {
+                unsigned w[12];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {   // v0 v0 v0 v1 | v1 v1 v2 v2 | v2 v3 v3 v3
+                    w[3 * q + 0] = __builtin_amdgcn_perm(0u, e4[q], 0x01000000u);
+                    w[3 * q + 1] = __builtin_amdgcn_perm(0u, e4[q], 0x02020101u);
+                    w[3 * q + 2] = __builtin_amdgcn_perm(0u, e4[q], 0x03030302u);
+                }
+#pragma unroll
+                for (int q = 0; q < 3; q++) dst4[3 * c + q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; q++)     // v v v 255 per pixel (lidar.py:150-152: opaque alpha)
+                    dst4[4 * c + q] = make_uint4(__builtin_amdgcn_perm(0u, e4[q], 0x0d000000u), __builtin_amdgcn_perm(0u, e4[q], 0x0d010101u),
+                                                 __builtin_amdgcn_perm(0u, e4[q], 0x0d020202u), __builtin_amdgcn_perm(0u, e4[q], 0x0d030303u));
             }
-            reinterpret_cast<uint4 *>(dst)[c] = v;
-        }
-    } else if (ch == 4) {
-        for (int p = tid; p < rows * cols; p += BM_THREADS) {
-            const int y = p / cols, x = p - y * cols;
-            const unsigned v = bg ^ (bm_bit(anyp, S, x, y) ? flip : 0u);
-            reinterpret_cast<unsigned *>(dst)[p] = v * 0x00010101u | 0xff000000u; // lidar.py:150-152: opaque alpha
         }
     } else {
         for (size_t o = tid; o < img_bytes; o += BM_THREADS) {
-            const int p = (int)(o / ch), y = p / cols, x = p - y * cols;
-            dst[o] = (unsigned char)(bg ^ (bm_bit(anyp, S, x, y) ? flip : 0u)); // ch is 1 or 3 here
+            const int p = (int)(o / ch), c = (int)(o - (size_t)p * ch), y = p / cols, x = p - y * cols;
+            const unsigned bit = (anyp[y * S + (x >> 5)] >> (x & 31)) & 1u;
+            dst[o] = c == 3 ? (unsigned char)255 : (unsigned char)(bit ? a.draw : a.bg);
         }
     }
 }
@@ -388,7 +402,15 @@ __global__ __launch_bounds__(BM_THREADS) void occupancy_kernel(OccArgs a)
     }
     __syncthreads();
     unsigned char *dst = a.out + (size_t)img * G * G;
-    for (int p = tid; p < G * G; p += BM_THREADS) dst[p] = (unsigned char)((bits[p >> 5] >> (p & 31)) & 1u);
+    if ((G * G) % 16 == 0) {
+        for (int c = tid; c < G * G / 16; c += BM_THREADS) {
+            const unsigned h = (bits[c >> 1] >> ((c & 1) * 16)) & 0xffffu;
+            reinterpret_cast<uint4 *>(dst)[c] = make_uint4(bm_expand4(h & 15u, 0x0100u), bm_expand4((h >> 4) & 15u, 0x0100u),
+                                                           bm_expand4((h >> 8) & 15u, 0x0100u), bm_expand4(h >> 12, 0x0100u));
+        }
+    } else {
+        for (int p = tid; p < G * G; p += BM_THREADS) dst[p] = (unsigned char)((bits[p >> 5] >> (p & 31)) & 1u);
+    }
 }
 
 } // namespace f110
