@@ -55,8 +55,9 @@ struct alignas(16) EdgeRec {
 
 __host__ __device__ inline size_t bitmap_lds_bytes(int T, int rows, int S)
 {
-    // EdgeRec[T] | pts int2[T] | start int[T+1] | any[rows*S] | par[rows*S] | carry[rows]
-    return (size_t)T * sizeof(EdgeRec) + (size_t)T * 8 + (size_t)(T + 1) * 4 + (size_t)rows * S * 4 * 2 + (size_t)rows * 4;
+    // EdgeRec[T] | { par[rows*S] | carry bits[rows/32] } overlaid on { pts int2[T] } | start int[T+1] | any[rows*S]
+    const size_t par = (size_t)rows * S * 4 + (size_t)((rows + 31) / 32) * 4, pts = (size_t)T * 8;
+    return (size_t)T * sizeof(EdgeRec) + (size_t)(T + 1) * 4 + (size_t)rows * S * 4 + (par > pts ? par : pts);
 }
 
 // cv::clipLine(Size2l, Point2l&, Point2l&), drawing.cpp
@@ -186,6 +187,21 @@ __device__ inline int bm_find(const int *start, int n, int j)
     return lo;
 }
 
+typedef unsigned bm_v4u __attribute__((ext_vector_type(4)));
+#ifndef F110_BM_NT
+#define F110_BM_NT 1
+#endif
+// One 16-byte store of the output image (written once, never read back by this kernel).  STREAM: the wave's
+// lanes write consecutive 16-byte pieces (whole lines per instruction) -> non-temporal; lane-strided pieces
+// are left to the L2 to merge (measured: non-temporal partial lines cost 2.6x on the 3-channel path).
+template <bool STREAM>
+__device__ inline void bm_store16(void *p, unsigned a, unsigned b, unsigned c, unsigned d)
+{
+    const bm_v4u v = {a, b, c, d};
+    if (STREAM && F110_BM_NT) __builtin_nontemporal_store(v, reinterpret_cast<bm_v4u *>(p));
+    else *reinterpret_cast<bm_v4u *>(p) = v;
+}
+
 // 4 pixel bits -> 4 bytes, each bg (bit 0) or draw (bit 1); cols = bg | draw << 8
 __device__ inline unsigned bm_expand4(unsigned nib, unsigned cols2)
 {
@@ -199,16 +215,17 @@ __global__ __launch_bounds__(BM_THREADS) void bitmap_kernel(BitmapArgs a)
     __shared__ int s_wave[BM_THREADS / 64];
     const int T = a.T, rows = a.rows, cols = a.cols, S = a.S, tid = threadIdx.x, mode = a.mode;
     EdgeRec *recs = reinterpret_cast<EdgeRec *>(s_raw);
-    int2 *pts = reinterpret_cast<int2 *>(s_raw + (size_t)T * sizeof(EdgeRec));
-    int *start = reinterpret_cast<int *>(pts + T);
+    unsigned *parp = reinterpret_cast<unsigned *>(s_raw + (size_t)T * sizeof(EdgeRec));
+    unsigned *carry = parp + rows * S;                   // one bit per row
+    int2 *pts = reinterpret_cast<int2 *>(parp);          // dead once the records exist; par / carry are zeroed after that
+    const int par_words = rows * S + (rows + 31) / 32;
+    int *start = reinterpret_cast<int *>(parp + max(par_words, 2 * T));
     unsigned *anyp = reinterpret_cast<unsigned *>(start + T + 1);
-    unsigned *parp = anyp + rows * S;
-    unsigned *carry = parp + rows * S;
 
     const int img = blockIdx.x;
     const int cx = rows / 2, cy = cols / 2; // lidar.py:75: center = (dims[0]//2, dims[1]//2), used as (x, y)
 
-    for (int i = tid; i < rows * S * 2 + rows; i += BM_THREADS) anyp[i] = 0u;
+    for (int i = tid; i < rows * S; i += BM_THREADS) anyp[i] = 0u;
     // lidar.py:70-81: points = rint(center + (scaling_factor * data) * {cos, sin}(angles)).astype(int)
     for (int k = tid; k < T; k += BM_THREADS) {
         const long long o = (long long)img * a.stride + a.idx[k];
@@ -243,6 +260,7 @@ __global__ __launch_bounds__(BM_THREADS) void bitmap_kernel(BitmapArgs a)
         if (q < per && i < T) { start[i] = base; base += cnt[q]; }
     }
     if (tid == 0) start[T] = total;
+    for (int i = tid; i < par_words; i += BM_THREADS) parp[i] = 0u;   // every thread is past its pts reads (barrier in the scan)
     if (a.draw_center && mode != BM_FILL && tid < 25) {
         // lidar.py:98-100: centre marker in the draw colour (FILL clears it after the fill, below)
         const int x = cx - 2 + tid % 5, y = cy - 2 + tid / 5;
@@ -291,7 +309,7 @@ __global__ __launch_bounds__(BM_THREADS) void bitmap_kernel(BitmapArgs a)
                     const int y = (int)(r.rows & 0xffffu) + (k - L);
                     const long long X = xr >> BM_XY_SHIFT;
                     xr += r.dx;
-                    if (X < 0) atomicXor(&carry[y], 1u);
+                    if (X < 0) atomicXor(&carry[y >> 5], 1u << (y & 31));
                     else if (X < cols) {
                         atomicXor(&parp[y * S + (int)(X >> 5)], 1u << (X & 31));
                         bm_set(anyp, S, (int)X, y);
@@ -309,7 +327,7 @@ __global__ __launch_bounds__(BM_THREADS) void bitmap_kernel(BitmapArgs a)
     if (mode == BM_FILL) {
         // ---- inside = crossing on the pixel, or an odd number of crossings strictly left of it; then the centre marker
         for (int y = tid; y < rows; y += BM_THREADS) {
-            unsigned c = carry[y] & 1u;
+            unsigned c = (carry[y >> 5] >> (y & 31)) & 1u;
             const bool marker_row = a.draw_center && y >= cy - 2 && y <= cy + 2;
             for (int w = 0; w < S; w++) {
                 unsigned p = parp[y * S + w];
@@ -332,32 +350,38 @@ __global__ __launch_bounds__(BM_THREADS) void bitmap_kernel(BitmapArgs a)
     unsigned char *dst = a.out + (size_t)img * img_bytes;
     const unsigned cols2 = ((unsigned)a.bg & 255u) | ((unsigned)a.draw & 255u) << 8;
     if ((cols & 15) == 0) {
-        // 16 pixels (half a plane word) per step: 16 / 48 / 64 output bytes as 16-byte stores
-        const int chunks = rows * cols / 16, cpr = cols / 16;
         uint4 *dst4 = reinterpret_cast<uint4 *>(dst);
-        for (int c = tid; c < chunks; c += BM_THREADS) {
-            const int y = c / cpr, h = c - y * cpr;
-            const unsigned bits = (anyp[y * S + (h >> 1)] >> ((h & 1) * 16)) & 0xffffu;
-            unsigned e4[4];
+        if (ch == 4) {
+            // 4 pixels -> 16 bytes "v v v 255" each (lidar.py:150-152: opaque alpha), lanes contiguous
+            const int quads = rows * cols / 4, qpr = cols / 4;
+            for (int c = tid; c < quads; c += BM_THREADS) {
+                const int y = c / qpr, h = c - y * qpr;
+                const unsigned e = bm_expand4((anyp[y * S + (h >> 3)] >> ((h & 7) * 4)) & 15u, cols2);
+                bm_store16<true>(dst4 + c, __builtin_amdgcn_perm(0u, e, 0x0d000000u), __builtin_amdgcn_perm(0u, e, 0x0d010101u),
+                                 __builtin_amdgcn_perm(0u, e, 0x0d020202u), __builtin_amdgcn_perm(0u, e, 0x0d030303u));
+            }
+        } else {
+            // 16 pixels (half a plane word) per step: 16 or 48 output bytes as 16-byte stores
+            const int chunks = rows * cols / 16, cpr = cols / 16;
+            for (int c = tid; c < chunks; c += BM_THREADS) {
+                const int y = c / cpr, h = c - y * cpr;
+                const unsigned bits = (anyp[y * S + (h >> 1)] >> ((h & 1) * 16)) & 0xffffu;
+                unsigned e4[4];
 #pragma unroll
-            for (int q = 0; q < 4; q++) e4[q] = bm_expand4((bits >> (4 * q)) & 15u, cols2);
-            if (ch == 1) {
-                dst4[c] = make_uint4(e4[0], e4[1], e4[2], e4[3]);
-            } else if (ch == 3) {
-                unsigned w[12];
+                for (int q = 0; q < 4; q++) e4[q] = bm_expand4((bits >> (4 * q)) & 15u, cols2);
+                if (ch == 1) {
+                    bm_store16<true>(dst4 + c, e4[0], e4[1], e4[2], e4[3]);
+                } else {
+                    unsigned w[12];
 #pragma unroll
-                for (int q = 0; q < 4; q++) {   // v0 v0 v0 v1 | v1 v1 v2 v2 | v2 v3 v3 v3
-                    w[3 * q + 0] = __builtin_amdgcn_perm(0u, e4[q], 0x01000000u);
-                    w[3 * q + 1] = __builtin_amdgcn_perm(0u, e4[q], 0x02020101u);
-                    w[3 * q + 2] = __builtin_amdgcn_perm(0u, e4[q], 0x03030302u);
+                    for (int q = 0; q < 4; q++) {   // v0 v0 v0 v1 | v1 v1 v2 v2 | v2 v3 v3 v3
+                        w[3 * q + 0] = __builtin_amdgcn_perm(0u, e4[q], 0x01000000u);
+                        w[3 * q + 1] = __builtin_amdgcn_perm(0u, e4[q], 0x02020101u);
+                        w[3 * q + 2] = __builtin_amdgcn_perm(0u, e4[q], 0x03030302u);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 3; q++) bm_store16<false>(dst4 + 3 * c + q, w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
                 }
-#pragma unroll
-                for (int q = 0; q < 3; q++) dst4[3 * c + q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
-            } else {
-#pragma unroll
-                for (int q = 0; q < 4; q++)     // v v v 255 per pixel (lidar.py:150-152: opaque alpha)
-                    dst4[4 * c + q] = make_uint4(__builtin_amdgcn_perm(0u, e4[q], 0x0d000000u), __builtin_amdgcn_perm(0u, e4[q], 0x0d010101u),
-                                                 __builtin_amdgcn_perm(0u, e4[q], 0x0d020202u), __builtin_amdgcn_perm(0u, e4[q], 0x0d030303u));
             }
         }
     } else {
@@ -405,8 +429,8 @@ __global__ __launch_bounds__(BM_THREADS) void occupancy_kernel(OccArgs a)
     if ((G * G) % 16 == 0) {
         for (int c = tid; c < G * G / 16; c += BM_THREADS) {
             const unsigned h = (bits[c >> 1] >> ((c & 1) * 16)) & 0xffffu;
-            reinterpret_cast<uint4 *>(dst)[c] = make_uint4(bm_expand4(h & 15u, 0x0100u), bm_expand4((h >> 4) & 15u, 0x0100u),
-                                                           bm_expand4((h >> 8) & 15u, 0x0100u), bm_expand4(h >> 12, 0x0100u));
+            bm_store16<true>(reinterpret_cast<uint4 *>(dst) + c, bm_expand4(h & 15u, 0x0100u), bm_expand4((h >> 4) & 15u, 0x0100u),
+                       bm_expand4((h >> 8) & 15u, 0x0100u), bm_expand4(h >> 12, 0x0100u));
         }
     } else {
         for (int p = tid; p < G * G; p += BM_THREADS) dst[p] = (unsigned char)((bits[p >> 5] >> (p & 31)) & 1u);
