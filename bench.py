@@ -153,6 +153,9 @@ def main():
     ap.add_argument('--agents', type=int, default=1)
     ap.add_argument('--policy', choices=['random', 'pure_pursuit'], default='random',
                     help='random actions (the headline workload, SURVEY 8d) or closed-loop pure pursuit on the GPU')
+    ap.add_argument('--bitmap', choices=['none', 'FILL', 'POLYGON', 'RAYS'], default='none',
+                    help="secondary mode: also draw every ego scan to a 256x256 bird's-eye bitmap after each step "
+                         '(lidar_to_bitmap, what the RL consumers do with the scans)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-scan-events', action='store_true',
                     help='do not bracket the scan kernel with hipEvents (roofline becomes null)')
@@ -183,8 +186,6 @@ def main():
         env.step(acts[k % POOL])
     lookups = env.eng.t['lookups']
     lookups.zero_()
-    if not args.no_scan_events:
-        env.eng.profile_begin(K)
     if args.policy == 'pure_pursuit':
         # secondary mode: the reference's waypoint follower runs on the GPU in front of every step
         rl = workload.load_waypoints(workload.RACELINE)
@@ -195,6 +196,19 @@ def main():
         lookups.zero_()
     else:
         step_fn = lambda k: env.step(acts[(W + k) % POOL])  # noqa: E731
+    if args.bitmap != 'none':
+        from red_gym_amd.lidar import LidarBitmap
+        to_img = LidarBitmap(1080, bg_color='black', draw_mode=args.bitmap, device=local_rank)
+        imgs = torch.empty((B, 256, 256), dtype=torch.uint8, device=dev)
+        inner = step_fn
+
+        def step_fn(k):  # noqa: F811
+            obs = inner(k)[0]
+            to_img(obs['scans'][:, 0], out=imgs)
+        step_fn(0)
+        lookups.zero_()
+    if not args.no_scan_events:
+        env.eng.profile_begin(K)  # hipEvent pair around each of the K timed scan launches
     elapsed = timed_steps(ranks, step_fn, K)
 
     out = None
@@ -230,7 +244,8 @@ def main():
                'config': {'workload': '%d envs x %d agent(s) per GPU, example_map, 1080 beams, RK4 single-track, '
                                       'noise+iTTC%s, lap logic, autoreset; %s'
                                       % (B, A, '+GJK+opponent ray-cast' if A > 1 else '',
-                                         'random actions' if args.policy == 'random' else 'GPU pure-pursuit policy in the loop'),
+                                         ('random actions' if args.policy == 'random' else 'GPU pure-pursuit policy in the loop')
+                                         + ('' if args.bitmap == 'none' else '; + %s bitmap of every ego scan' % args.bitmap)),
                           'envs_per_gpu': B, 'agents': A, 'num_beams': 1080, 'map': 'example_map',
                           'sharding': 'independent env shards, no collective on the step path'},
                'roofline': roof}

@@ -19,6 +19,11 @@ pmc fetch FETCH_SIZE
 pmc write WRITE_SIZE
 pmc tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
 pmc tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum
+# 3. the scans' consumer: bitmap_kernel on 65536 scans (stats pass, then HBM write bytes in its own pass)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bitmap_stats -o bm -- python3 $ROOT/tools/bench_bitmap.py --reps 10 > $OUT/bitmap_under_rocprof.txt 2> $OUT/bitmap_stats.err
+echo "bitmap stats rc=$?"
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_bmwrite -o pmc -- python3 $ROOT/tools/bench_bitmap.py --reps 3 > $OUT/pmc_bmwrite.out 2> $OUT/pmc_bmwrite.err
+echo "pmc bmwrite rc=$?"
 cd $ROOT
 python3 tools/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt

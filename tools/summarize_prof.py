@@ -13,7 +13,7 @@ def find(pattern):
 
 
 print('== kernel stats (rocprofv3 --kernel-trace --stats) ==')
-for f in find('stats/**/*kernel_stats.csv'):
+for f in find('stats/**/*kernel_stats.csv') + find('bitmap_stats/**/*kernel_stats.csv'):
     for row in csv.DictReader(open(f)):
         print('%-70s calls %6s  avg_us %10.2f  total_ms %10.3f  pct %6s' % (
             row['Name'][:70], row['Calls'], float(row['AverageNs']) / 1e3, float(row['TotalDurationNs']) / 1e6,
@@ -23,11 +23,14 @@ print('== bench line under rocprof ==')
 for f in find('bench_under_rocprof.json'):
     print(open(f).read().strip()[-900:])
 print()
-print('== PMC counters: mean per dispatch of scan_kernel ==')
+for f in find('bitmap_under_rocprof.txt'):
+    print(open(f).read().strip()[-600:])
+print()
+print('== PMC counters: mean per dispatch of scan_kernel (bmwrite: of bitmap_kernel) ==')
 for f in find('pmc_*/**/*counter_collection.csv'):
     acc, cnt = defaultdict(float), defaultdict(int)
     for row in csv.DictReader(open(f)):
-        if 'scan_kernel' not in row['Kernel_Name']:
+        if ('bitmap_kernel' if 'bmwrite' in f else 'scan_kernel') not in row['Kernel_Name']:
             continue
         acc[row['Counter_Name']] += float(row['Counter_Value'])
         cnt[row['Counter_Name']] += 1
