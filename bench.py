@@ -165,9 +165,13 @@ def main():
     from red_gym_amd import F110VecEnv, workload
 
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    # Rehearsal hooks for a one-GPU box (the driver's runs use neither): F110_BENCH_ONE_DEVICE=1 puts every
+    # rank on device 0 and F110_BENCH_BACKEND=gloo replaces RCCL, which refuses two ranks on one device.
+    if os.environ.get('F110_BENCH_ONE_DEVICE') == '1':
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    ranks = Ranks('nccl', dev)
+    ranks = Ranks(os.environ.get('F110_BENCH_BACKEND', 'nccl'), dev)
     rank, world = ranks.rank, ranks.world
     if world != args.gpus:
         if world == 1 and args.gpus > 1:

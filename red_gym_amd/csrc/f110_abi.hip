@@ -318,6 +318,7 @@ extern "C" int f110_set_tables(f110_handle *h, const double *sines, const double
 {
     if (!h) return fail(F110_E_INVALID, "f110_set_tables: null handle");
     HIP_TRY(hipSetDevice(h->cfg.device));
+    HIP_TRY(hipDeviceSynchronize()); // enqueued steps may still read the tables being replaced
     int rc = F110_OK;
     if (sines) h->h_sines.assign(sines, sines + h->cfg.theta_dis);
     if (cosines) h->h_cosines.assign(cosines, cosines + h->cfg.theta_dis);
@@ -503,7 +504,8 @@ static ScanDev scan_dev(const f110_handle *h)
 template <bool STEP>
 static int launch_scan_t(f110_handle *h, const ScanArgs &a, hipStream_t st)
 {
-    const dim3 grid((a.n_cars * a.wpc + SCAN_WAVES - 1) / SCAN_WAVES), block(SCAN_THREADS);
+    const int waves = a.wpc == 1 ? (a.n_cars - a.n_tail) + a.n_tail * TAIL_WPC : a.n_cars * a.wpc;
+    const dim3 grid((waves + SCAN_WAVES - 1) / SCAN_WAVES), block(SCAN_THREADS);
     if (h->ident && h->pow2) hipLaunchKernelGGL((scan_kernel<true, true, STEP>), grid, block, 0, st, a);
     else if (h->ident) hipLaunchKernelGGL((scan_kernel<true, false, STEP>), grid, block, 0, st, a);
     else if (h->pow2) hipLaunchKernelGGL((scan_kernel<false, true, STEP>), grid, block, 0, st, a);
@@ -531,6 +533,17 @@ static int launch_scan(f110_handle *h, const ScanArgs &a_in, hipStream_t st)
 {
     ScanArgs a = a_in;
     a.wpc = waves_per_car(a.n_cars, a.scan.nb);
+    // Drain of a launch: workgroups are dispatched in index order and nothing follows the last ones,
+    // so the chip empties over one wave lifetime (about half of it lost: ~5 % at 65 536 cars -- the gap
+    // that two half-size launches from two processes close by overlapping).  The last cars therefore
+    // run as TAIL_WPC short waves each.  Measured (gpurun_out sweeps, profiles/r01j): 65 536 cars
+    // 0.702 -> 0.672 ms for any tail of 1 000 .. 2 048 cars (it has to cover the last of the slowest
+    // cars), 32 768: 0.380 -> 0.368, 16 384: 0.225 -> 0.218, 8 192: neutral, 4 096: 0.126 -> 0.105 with
+    // half of the cars split.  F110_TAIL_CARS overrides the count.
+    static const char *tail_env = getenv("F110_TAIL_CARS");
+    int n_tail = 0;
+    if (a.wpc == 1 && (a.scan.nb + 63) / 64 >= TAIL_WPC) n_tail = tail_env ? atoi(tail_env) : std::min(2048, a.n_cars / 2);
+    a.n_tail = std::max(0, std::min(n_tail, a.n_cars));
     return a.state ? launch_scan_t<true>(h, a, st) : launch_scan_t<false>(h, a, st);
 }
 

@@ -205,6 +205,7 @@ struct ScanArgs {
     int agents;             // A (cars of one env are consecutive)
     int wpc;                // wavefronts per car (power of two): small batches split a car's beams over
                             // several waves so that the chip is still filled; chunk position p goes to wave p % wpc
+    int n_tail;             // wpc == 1 only: the LAST n_tail cars run as TAIL_WPC short waves each (see launch_scan)
     // pose source: pose = (src[car*stride], src[car*stride+1], src[car*stride+yaw_off])
     const double *pose_src;
     int pose_stride, yaw_off;
@@ -231,6 +232,10 @@ struct ScanArgs {
 // use is the 8 KiB distance LUT shared by the workgroup, so occupancy is register-bound.
 // STEP: full env step (noise + iTTC + state update); false: ScanSimulator2D.scan(pose, None).
 constexpr int MAX_CHUNKS = 64; // beams are handed out in chunks of 64 (num_beams <= 4096)
+#ifndef F110_TAIL_WPC
+#define F110_TAIL_WPC 4
+#endif
+constexpr int TAIL_WPC = F110_TAIL_WPC; // waves per car for the last cars of a big launch
 
 template <bool IDENT, bool POW2, bool STEP>
 #ifndef F110_SCAN_MIN_WAVES
@@ -254,8 +259,16 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int wid = blockIdx.x * SCAN_WAVES + wave; // wave-uniform (scalar)
-    const int wpc = a.wpc;
-    const int car = wid / wpc, part = wid % wpc;
+    // wave -> (car, part of its beam queue).  Kept to one extra argument and shifts: this kernel sits at
+    // the 80-SGPR budget of 8 waves/SIMD, and a scalar spilled inside the refill loop costs ~3 % of the launch.
+    int wpc = a.wpc, car, part;
+    if (wpc == 1) {
+        const int head = a.n_cars - a.n_tail;
+        if (wid < head) { car = wid; part = 0; }
+        else { wpc = TAIL_WPC; car = head + (wid - head) / TAIL_WPC; part = (wid - head) % TAIL_WPC; }
+    } else {
+        car = wid / wpc; part = wid % wpc;
+    }
     if (car >= a.n_cars) return;
     // this wave's slice of the car's beam queue: chunk positions part, part+wpc, ...
     const int nch = (nb + 63) >> 6;
