@@ -119,6 +119,11 @@ int f110_set_tables(f110_handle *h, const double *sines_host, const double *cosi
 int f110_set_map_occupancy(f110_handle *h, const uint8_t *free_mask_host, int32_t height,
                            int32_t width, double resolution, double orig_x, double orig_y,
                            double orig_c, double orig_s);
+/* Same with the mask already on the device (e.g. drawn by a track generator): the whole pipeline -- EDT,
+ * rank coding, LUT, fp64 table -- runs on the GPU; only two scalars and the 8 KiB LDS image of the LUT visit
+ * the host.  An all-free mask (no occupied cell) is the caller's responsibility here. */
+int f110_set_map_occupancy_dev(f110_handle *h, const uint8_t *free_mask_dev, int32_t height, int32_t width,
+                               double resolution, double orig_x, double orig_y, double orig_c, double orig_s);
 /* Same, from a precomputed distance table dt = resolution*edt(img) (host, [H*W] fp64). */
 int f110_set_map_dt(f110_handle *h, const double *dt_host, int32_t height, int32_t width,
                     double resolution, double orig_x, double orig_y, double orig_c, double orig_s);
@@ -128,6 +133,9 @@ int f110_get_map_dt(f110_handle *h, double *dt_host_out);
 /* Exact squared Euclidean distance transform on the host (cells to nearest
  * zero cell), the integer kernel behind f110_set_map_occupancy. */
 int f110_edt_squared(const uint8_t *free_mask_host, int32_t height, int32_t width, uint32_t *d2_out_host);
+/* The same transform on the GPU (dev pointers; synchronises `stream` before returning): a column pass and a
+ * row pass with the row's g^2 in LDS, exact like the host version.  height, width <= 32768. */
+int f110_edt_squared_dev(const uint8_t *free_mask_dev, int32_t height, int32_t width, uint32_t *d2_out_dev, void *stream);
 
 /* Lidar noise: table[k] = k-th `rng.normal(0, std, num_beams)` draw of
  * default_rng(seed) (laser_models.py:450-452, base_classes.py:202), [T,num_beams]

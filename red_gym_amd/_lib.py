@@ -51,9 +51,11 @@ SYMBOLS = {
     'f110_update_params': [_VP, _VP, _I32],
     'f110_set_tables': [_VP, _VP, _VP, _VP, _VP, _VP],
     'f110_set_map_occupancy': [_VP, _VP, _I32, _I32, _D, _D, _D, _D, _D],
+    'f110_set_map_occupancy_dev': [_VP, _VP, _I32, _I32, _D, _D, _D, _D, _D],
     'f110_set_map_dt': [_VP, _VP, _I32, _I32, _D, _D, _D, _D, _D],
     'f110_get_map_dt': [_VP, _VP],
     'f110_edt_squared': [_VP, _I32, _I32, _VP],
+    'f110_edt_squared_dev': [_VP, _I32, _I32, _VP, _VP],
     'f110_set_noise_table': [_VP, _VP, _I64],
     'f110_bind': [_VP, C.POINTER(Buffers)],
     'f110_reset': [_VP, _VP, _VP, _VP],

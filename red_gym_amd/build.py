@@ -8,7 +8,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, 'csrc', 'f110_abi.hip')
-DEPS = [SRC, os.path.join(HERE, 'csrc', 'f110_kernels.h'), os.path.join(HERE, 'csrc', 'f110_device.h'), os.path.join(HERE, 'csrc', 'f110_bitmap.h'),
+DEPS = [SRC, os.path.join(HERE, 'csrc', 'f110_kernels.h'), os.path.join(HERE, 'csrc', 'f110_device.h'), os.path.join(HERE, 'csrc', 'f110_bitmap.h'), os.path.join(HERE, 'csrc', 'f110_mapgen.h'), os.path.join(HERE, 'csrc', 'f110_planner.h'),
         os.path.join(os.path.dirname(HERE), 'include', 'f110_hip.h')]
 LIB = os.path.join(HERE, 'libf110_hip.so')
 

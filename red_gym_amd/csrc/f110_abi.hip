@@ -6,6 +6,7 @@
 #include "f110_kernels.h"
 #include "f110_planner.h"
 #include "f110_bitmap.h"
+#include "f110_mapgen.h"
 
 #include <algorithm>
 #include <cmath>
@@ -73,7 +74,7 @@ extern "C" const char *f110_last_error(void) { return g_err; }
 // (exact Euclidean distances; reference call site laser_models.py:52).
 extern "C" int f110_edt_squared(const uint8_t *mask, int32_t H, int32_t W, uint32_t *d2)
 {
-    if (!mask || !d2 || H <= 0 || W <= 0) return fail(F110_E_INVALID, "f110_edt_squared: bad arguments");
+    if (!mask || !d2 || H <= 0 || W <= 0 || H > 32768 || W > 32768) return fail(F110_E_INVALID, "f110_edt_squared: bad arguments (size 1..32768)");
     const int64_t INF = (int64_t)H + W + 1;
     std::vector<int64_t> g((size_t)H * W);
     bool any_zero = false;
@@ -333,6 +334,24 @@ extern "C" int f110_set_tables(f110_handle *h, const double *sines, const double
     return rc;
 }
 
+// Publishes the device tables of a freshly built map in the handle (both pipelines end here).
+static int finish_map(f110_handle *h, int H, int W, int Hp, size_t n_tiled, double res, double ox, double oy, double oc,
+                      double os, double oob)
+{
+    MapDev &m = h->map;
+    m.cells = h->d_cells; m.cells_far = h->d_cells_far; m.lut = h->d_lut; m.lut_lds = h->d_lut_lds; m.dt = h->d_dt;
+    m.H = H; m.W = W; m.strip_bytes = (unsigned)Hp * 16u; m.cells_bytes = (unsigned)(n_tiled * sizeof(uint16_t)); m.res = res; m.rinv = 1.0 / res;
+    m.ox = ox; m.oy = oy; m.oc = oc; m.os = os;
+    m.wres = W * res; // width * resolution (laser_models.py:79)
+    m.hres = H * res;
+    m.oob = oob;      // dt[-1, -1]
+    int e = 0;
+    h->pow2 = std::frexp(res, &e) == 0.5;
+    h->ident = (oc == 1.0 && os == 0.0);
+    h->has_map = true;
+    return F110_OK;
+}
+
 // Builds the device map from a host fp64 distance table (and, when known, its
 // exact squared form).  Cells whose value is not resolution*sqrt(integer) keep
 // the escape code and are served from the fp64 table.
@@ -382,6 +401,8 @@ static int install_map(f110_handle *h, const double *dt, const uint32_t *d2_or_n
     if (h->d_cells) { (void)hipFree(h->d_cells); h->d_cells = nullptr; }
     if (h->d_cells_far) { (void)hipFree(h->d_cells_far); h->d_cells_far = nullptr; }
     if (h->d_dt) { (void)hipFree(h->d_dt); h->d_dt = nullptr; }
+    if (h->d_lut) { (void)hipFree(h->d_lut); h->d_lut = nullptr; } // its length depends on the map
+    h->has_map = false;
     HIP_TRY(hipMalloc((void **)&h->d_cells, n_tiled * sizeof(uint16_t)));
     HIP_TRY(hipMalloc((void **)&h->d_dt, n * sizeof(double)));
     HIP_TRY(hipMemcpy(h->d_cells, cells.data(), n_tiled * sizeof(uint16_t), hipMemcpyHostToDevice));
@@ -394,19 +415,118 @@ static int install_map(f110_handle *h, const double *dt, const uint32_t *d2_or_n
     lut_lds[SLOT_FAR] = 0.0;          // never used as a distance (OFF_FAR cells take the second table)
     lut_lds[SLOT_BORDER] = dt[n - 1]; // dt[-1, -1]
     if ((rc = upload(&h->d_lut_lds, lut_lds.data(), lut_lds.size()))) return rc;
-    MapDev &m = h->map;
-    m.cells = h->d_cells; m.cells_far = h->d_cells_far; m.lut = h->d_lut; m.lut_lds = h->d_lut_lds; m.dt = h->d_dt;
-    m.H = H; m.W = W; m.strip_bytes = (unsigned)Hp * 16u; m.cells_bytes = (unsigned)(n_tiled * sizeof(uint16_t)); m.res = res; m.rinv = 1.0 / res;
-    m.ox = ox; m.oy = oy; m.oc = oc; m.os = os;
-    m.wres = W * res; // width * resolution (laser_models.py:79)
-    m.hres = H * res;
-    m.oob = dt[n - 1]; // dt[-1, -1]
-    int e = 0;
-    h->pow2 = std::frexp(res, &e) == 0.5;
-    h->ident = (oc == 1.0 && os == 0.0);
-    h->has_map = true;
+    return finish_map(h, H, W, Hp, n_tiled, res, ox, oy, oc, os, dt[n - 1]);
+}
+
+// ---------------------------------------------------------------- map pipeline on the device
+namespace {
+struct DevTemp { // frees its device scratch on every exit path
+    std::vector<void *> ptrs;
+    ~DevTemp() { for (void *p : ptrs) if (p) (void)hipFree(p); }
+    template <typename T> hipError_t alloc(T **out, size_t n)
+    {
+        void *p = nullptr;
+        const hipError_t e = hipMalloc(&p, n * sizeof(T));
+        if (e == hipSuccess) ptrs.push_back(p);
+        *out = static_cast<T *>(p);
+        return e;
+    }
+};
+} // namespace
+
+static int check_edt_size(int H, int W, const char *who)
+{
+    if (H < 1 || W < 1 || H > 32768 || W > 32768) return fail(F110_E_INVALID, "%s: map size %dx%d outside 1..32768", who, H, W);
     return F110_OK;
 }
+
+// exact squared EDT of a device mask into a device table; *max_d2_dev (optional) receives the largest value
+static int edt_squared_device(const uint8_t *mask_dev, int H, int W, uint32_t *d2_dev, unsigned *g_scratch, unsigned *max_d2_dev,
+                              hipStream_t st)
+{
+    hipLaunchKernelGGL(edt_columns_kernel, dim3((W + 255) / 256), dim3(256), 0, st, mask_dev, H, W, g_scratch);
+    HIP_TRY(hipGetLastError());
+    const size_t lds = (size_t)W * sizeof(unsigned);
+    if (lds > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void *)edt_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(edt_rows_kernel, dim3(H), dim3(256), lds, st, g_scratch, H, W, d2_dev, max_d2_dev);
+    HIP_TRY(hipGetLastError());
+    return F110_OK;
+}
+
+extern "C" int f110_edt_squared_dev(const uint8_t *mask_dev, int32_t H, int32_t W, uint32_t *d2_dev, void *stream)
+{
+    if (!mask_dev || !d2_dev) return fail(F110_E_INVALID, "f110_edt_squared_dev: null pointer");
+    int rc = check_edt_size(H, W, "f110_edt_squared_dev");
+    if (rc) return rc;
+    DevTemp tmp;
+    unsigned *g = nullptr;
+    HIP_TRY(tmp.alloc(&g, (size_t)H * W));
+    if ((rc = edt_squared_device(mask_dev, H, W, d2_dev, g, nullptr, (hipStream_t)stream))) return rc;
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream)); // the scratch is freed on return
+    return F110_OK;
+}
+
+// Occupancy mask (device) -> all map tables, without leaving the GPU.  mask: nonzero = free.
+static int install_map_occupancy_dev(f110_handle *h, const uint8_t *mask_dev, int H, int W, double res, double ox, double oy,
+                                     double oc, double os)
+{
+    const size_t n = (size_t)H * W;
+    const int strips = (W + 2 + 7) >> 3, Hp = ((H + 2 + 7) >> 3) << 3;
+    const size_t n_tiled = (size_t)strips * Hp * 8;
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    HIP_TRY(hipDeviceSynchronize()); // the previous map may still be in use by enqueued steps
+    hipStream_t st = nullptr;
+    DevTemp tmp;
+    unsigned *g = nullptr, *d2 = nullptr, *maxv = nullptr, *bits = nullptr, *prefix = nullptr, *sums = nullptr;
+    HIP_TRY(tmp.alloc(&g, n));
+    HIP_TRY(tmp.alloc(&d2, n));
+    HIP_TRY(tmp.alloc(&maxv, 2));
+    HIP_TRY(hipMemsetAsync(maxv, 0, 2 * sizeof(unsigned), st));
+    int rc = edt_squared_device(mask_dev, H, W, d2, g, maxv, st);
+    if (rc) return rc;
+    unsigned max_d2 = 0;
+    HIP_TRY(hipMemcpy(&max_d2, maxv, sizeof(unsigned), hipMemcpyDeviceToHost));
+    // ranks of the distinct d2 values: presence bitmap + exclusive prefix of its popcounts
+    const int n_words = (int)(((size_t)max_d2 + 32) / 32);
+    const int n_blocks = (n_words + SCAN_BLOCK_WORDS - 1) / SCAN_BLOCK_WORDS;
+    HIP_TRY(tmp.alloc(&bits, (size_t)n_words));
+    HIP_TRY(tmp.alloc(&prefix, (size_t)n_words));
+    HIP_TRY(tmp.alloc(&sums, (size_t)n_blocks));
+    HIP_TRY(hipMemsetAsync(bits, 0, (size_t)n_words * sizeof(unsigned), st));
+    hipLaunchKernelGGL(d2_mark_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d2, n, bits);
+    hipLaunchKernelGGL(rank_block_sums_kernel, dim3(n_blocks), dim3(256), 0, st, bits, n_words, sums);
+    hipLaunchKernelGGL(rank_scan_sums_kernel, dim3(1), dim3(64), 0, st, sums, n_blocks, maxv + 1);
+    hipLaunchKernelGGL(rank_word_prefix_kernel, dim3(n_blocks), dim3(256), 0, st, bits, n_words, sums, prefix);
+    HIP_TRY(hipGetLastError());
+    // the handle's tables
+    if (h->d_cells) { (void)hipFree(h->d_cells); h->d_cells = nullptr; }
+    if (h->d_cells_far) { (void)hipFree(h->d_cells_far); h->d_cells_far = nullptr; }
+    if (h->d_dt) { (void)hipFree(h->d_dt); h->d_dt = nullptr; }
+    if (h->d_lut) { (void)hipFree(h->d_lut); h->d_lut = nullptr; }
+    h->has_map = false;
+    HIP_TRY(hipMalloc((void **)&h->d_cells, n_tiled * sizeof(uint16_t)));
+    HIP_TRY(hipMalloc((void **)&h->d_cells_far, n_tiled * sizeof(uint16_t)));
+    HIP_TRY(hipMalloc((void **)&h->d_dt, n * sizeof(double)));
+    const unsigned n_lut = CODE_ESC; // ranks 0..65534 are encodable; unused slots stay 0.0
+    HIP_TRY(hipMalloc((void **)&h->d_lut, (size_t)n_lut * sizeof(double)));
+    HIP_TRY(hipMemsetAsync(h->d_lut, 0, (size_t)n_lut * sizeof(double), st));
+    hipLaunchKernelGGL(map_fill_border_kernel, dim3((unsigned)((n_tiled + 255) / 256)), dim3(256), 0, st, h->d_cells, h->d_cells_far, n_tiled);
+    hipLaunchKernelGGL(map_encode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d2, H, W, Hp, bits, prefix, res, h->d_cells,
+                       h->d_cells_far, h->d_dt);
+    hipLaunchKernelGGL(map_lut_kernel, dim3((n_words + 255) / 256), dim3(256), 0, st, bits, n_words, prefix, res, h->d_lut, n_lut);
+    HIP_TRY(hipGetLastError());
+    // LDS image of the LUT: its first slots, with the two special ones (see MapDev)
+    std::vector<double> lut_lds(LUT_LDS);
+    double oob = 0;
+    HIP_TRY(hipMemcpy(lut_lds.data(), h->d_lut, LUT_LDS * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&oob, h->d_dt + (n - 1), sizeof(double), hipMemcpyDeviceToHost));
+    lut_lds[SLOT_FAR] = 0.0;
+    lut_lds[SLOT_BORDER] = oob;
+    if ((rc = upload(&h->d_lut_lds, lut_lds.data(), lut_lds.size()))) return rc;
+    return finish_map(h, H, W, Hp, n_tiled, res, ox, oy, oc, os, oob);
+}
+
 
 static int check_map_args(f110_handle *h, const void *p, int H, int W, double res, const char *who)
 {
@@ -420,13 +540,23 @@ extern "C" int f110_set_map_occupancy(f110_handle *h, const uint8_t *mask, int32
                                       double ox, double oy, double oc, double os)
 {
     int rc = check_map_args(h, mask, H, W, res, "f110_set_map_occupancy");
-    if (rc) return rc;
+    if (rc || (rc = check_edt_size(H, W, "f110_set_map_occupancy"))) return rc;
     const size_t n = (size_t)H * W;
-    std::vector<uint32_t> d2(n);
-    if ((rc = f110_edt_squared(mask, H, W, d2.data()))) return rc;
-    std::vector<double> dt(n);
-    for (size_t i = 0; i < n; i++) dt[i] = res * std::sqrt((double)d2[i]);
-    return install_map(h, dt.data(), d2.data(), H, W, res, ox, oy, oc, os);
+    if (!memchr(mask, 0, n)) return fail(F110_E_INVALID, "f110_set_map_occupancy: map has no occupied cell");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    DevTemp tmp;
+    uint8_t *mask_dev = nullptr;
+    HIP_TRY(tmp.alloc(&mask_dev, n));
+    HIP_TRY(hipMemcpy(mask_dev, mask, n, hipMemcpyHostToDevice));
+    return install_map_occupancy_dev(h, mask_dev, H, W, res, ox, oy, oc, os);
+}
+
+extern "C" int f110_set_map_occupancy_dev(f110_handle *h, const uint8_t *mask_dev, int32_t H, int32_t W, double res,
+                                          double ox, double oy, double oc, double os)
+{
+    int rc = check_map_args(h, mask_dev, H, W, res, "f110_set_map_occupancy_dev");
+    if (rc || (rc = check_edt_size(H, W, "f110_set_map_occupancy_dev"))) return rc;
+    return install_map_occupancy_dev(h, mask_dev, H, W, res, ox, oy, oc, os);
 }
 
 extern "C" int f110_set_map_dt(f110_handle *h, const double *dt, int32_t H, int32_t W, double res, double ox,

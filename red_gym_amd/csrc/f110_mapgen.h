@@ -1,0 +1,188 @@
+// f110_mapgen.h -- the map pipeline on the GPU (map tooling): occupancy mask -> exact squared
+// Euclidean distance transform -> rank-coded cell table + fp64 LUT + fp64 distance table, i.e. everything
+// ScanSimulator2D.set_map (reference laser_models.py:383-427, get_dt :40-53) prepares, in ~1 ms instead of the
+// host's ~0.3 s, so that a map can be swapped per episode (domain randomisation) without stalling the step path.
+// Integer arithmetic throughout: d2 is exact, and resolution*sqrt(d2) (IEEE sqrt and multiply) reproduces
+// scipy.ndimage.distance_transform_edt bit for bit like the host pipeline it replaces.
+#pragma once
+#include "f110_kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace f110 {
+
+constexpr unsigned EDT_NONE = 0xffffffffu; // column without any occupied cell
+
+// Pass 1, one lane per column (coalesced across x): g = distance along the column to the nearest zero cell.
+__global__ __launch_bounds__(256) void edt_columns_kernel(const uint8_t *mask, int H, int W, unsigned *g)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= W) return;
+    unsigned d = EDT_NONE;
+    for (int y = 0; y < H; y++) {
+        const size_t i = (size_t)y * W + x;
+        d = mask[i] ? (d == EDT_NONE ? EDT_NONE : d + 1) : 0u;
+        g[i] = d;
+    }
+    d = EDT_NONE;
+    for (int y = H - 1; y >= 0; y--) {
+        const size_t i = (size_t)y * W + x;
+        d = mask[i] ? (d == EDT_NONE ? EDT_NONE : d + 1) : 0u;
+        const unsigned up = g[i];
+        g[i] = d < up ? d : up;
+    }
+}
+
+// Pass 2, one workgroup per row with the row's g^2 in LDS: d2(x) = min over x' of (x - x')^2 + g(x')^2, searched
+// outwards from x and stopped as soon as dx^2 alone reaches the best value -- O(distance) LDS reads per cell,
+// exact, no lower-envelope bookkeeping (the sequential formulation of the host code).
+__global__ __launch_bounds__(256) void edt_rows_kernel(const unsigned *g, int H, int W, unsigned *d2, unsigned *max_d2)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    unsigned *g2 = reinterpret_cast<unsigned *>(s_raw);
+    const int y = blockIdx.x;
+    for (int x = threadIdx.x; x < W; x += blockDim.x) {
+        const unsigned v = g[(size_t)y * W + x];
+        g2[x] = v == EDT_NONE ? EDT_NONE : v * v; // v <= 32768: fits
+    }
+    __syncthreads();
+    unsigned local_max = 0;
+    for (int x = threadIdx.x; x < W; x += blockDim.x) {
+        unsigned long long best = g2[x] == EDT_NONE ? ~0ull : g2[x];
+        for (unsigned dx = 1; (unsigned long long)dx * dx < best && (x >= (int)dx || x + (int)dx < W); dx++) {
+            const unsigned long long q = (unsigned long long)dx * dx;
+            if (x >= (int)dx) {
+                const unsigned v = g2[x - dx];
+                if (v != EDT_NONE && q + v < best) best = q + v;
+            }
+            if (x + (int)dx < W) {
+                const unsigned v = g2[x + dx];
+                if (v != EDT_NONE && q + v < best) best = q + v;
+            }
+        }
+        const unsigned out = (unsigned)best; // the caller guarantees an occupied cell exists and H, W <= 32768
+        d2[(size_t)y * W + x] = out;
+        local_max = out > local_max ? out : local_max;
+    }
+    if (max_d2) {
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned o = __shfl_down(local_max, off, 64);
+            local_max = o > local_max ? o : local_max;
+        }
+        if ((threadIdx.x & 63) == 0) atomicMax(max_d2, local_max);
+    }
+}
+
+// presence bitmap of the distinct d2 values
+__global__ __launch_bounds__(256) void d2_mark_kernel(const unsigned *d2, size_t n, unsigned *bits)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned v = d2[i];
+    const unsigned m = 1u << (v & 31);
+    if (!(bits[v >> 5] & m)) atomicOr(&bits[v >> 5], m); // most values are already marked: read before the atomic
+}
+
+// exclusive prefix of per-word popcounts, three small kernels (1024 words per block)
+constexpr int SCAN_BLOCK_WORDS = 1024;
+__global__ __launch_bounds__(256) void rank_block_sums_kernel(const unsigned *bits, int n_words, unsigned *block_sums)
+{
+    __shared__ unsigned s_part[4];
+    unsigned c = 0;
+    for (int k = 0; k < 4; k++) {
+        const int w = blockIdx.x * SCAN_BLOCK_WORDS + k * 256 + threadIdx.x;
+        if (w < n_words) c += __popc(bits[w]);
+    }
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+}
+
+__global__ __launch_bounds__(64) void rank_scan_sums_kernel(unsigned *block_sums, int n_blocks, unsigned *total)
+{
+    // one wave, sequential over chunks of 64: n_blocks is small (words / 1024)
+    unsigned run = 0;
+    for (int base = 0; base < n_blocks; base += 64) {
+        const int i = base + threadIdx.x;
+        const unsigned v = i < n_blocks ? block_sums[i] : 0u;
+        unsigned incl = v;
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned t = __shfl_up(incl, off, 64);
+            if ((int)threadIdx.x >= off) incl += t;
+        }
+        if (i < n_blocks) block_sums[i] = run + incl - v;
+        run += __shfl(incl, 63, 64);
+    }
+    if (threadIdx.x == 0) *total = run;
+}
+
+__global__ __launch_bounds__(256) void rank_word_prefix_kernel(const unsigned *bits, int n_words, const unsigned *block_sums,
+                                                               unsigned *word_prefix)
+{
+    __shared__ unsigned s_wave[4];
+    // thread t owns words base + 4t .. 4t+3 (consecutive, so the in-block order is the word order)
+    const int w0 = blockIdx.x * SCAN_BLOCK_WORDS + threadIdx.x * 4;
+    unsigned c[4], sum = 0;
+    for (int k = 0; k < 4; k++) { c[k] = (w0 + k < n_words) ? __popc(bits[w0 + k]) : 0u; sum += c[k]; }
+    unsigned incl = sum;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    unsigned base = block_sums[blockIdx.x];
+    for (int w = 0; w < wave; w++) base += s_wave[w];
+    unsigned run = base + incl - sum;
+    for (int k = 0; k < 4; k++) {
+        if (w0 + k < n_words) word_prefix[w0 + k] = run;
+        run += c[k];
+    }
+}
+
+__device__ inline unsigned d2_rank(const unsigned *bits, const unsigned *word_prefix, unsigned v)
+{
+    return word_prefix[v >> 5] + __popc(bits[v >> 5] & ((1u << (v & 31)) - 1u));
+}
+
+// cell codes (strip layout with border, see MapDev), second rank table and the fp64 distance table
+__global__ __launch_bounds__(256) void map_encode_kernel(const unsigned *d2, int H, int W, int Hp, const unsigned *bits,
+                                                         const unsigned *word_prefix, double res, uint16_t *cells,
+                                                         uint16_t *cells_far, double *dt)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)H * W) return;
+    const unsigned v = d2[i];
+    const unsigned rank = d2_rank(bits, word_prefix, v);
+    const size_t r = i / W + 1, c = i % W + 1;
+    const size_t t = ((c >> 3) * (size_t)Hp + r) * 8 + (c & 7);
+    cells[t] = (uint16_t)(rank < SLOT_FAR ? 8u * rank : OFF_FAR);
+    cells_far[t] = (uint16_t)(rank < CODE_ESC ? rank : CODE_ESC);
+    dt[i] = res * sqrt((double)v);
+}
+
+__global__ __launch_bounds__(256) void map_fill_border_kernel(uint16_t *cells, uint16_t *cells_far, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    cells[i] = (uint16_t)OFF_BORDER;
+    cells_far[i] = 0;
+}
+
+// lut[rank] = resolution * sqrt(d2) for every distinct d2 with rank < n_lut
+__global__ __launch_bounds__(256) void map_lut_kernel(const unsigned *bits, int n_words, const unsigned *word_prefix, double res,
+                                                      double *lut, unsigned n_lut)
+{
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_words) return;
+    unsigned b = bits[w], rank = word_prefix[w];
+    while (b && rank < n_lut) {
+        const int bit = __ffs(b) - 1;
+        b &= b - 1;
+        lut[rank++] = res * sqrt((double)((unsigned)w * 32u + (unsigned)bit));
+    }
+}
+
+} // namespace f110

@@ -186,6 +186,26 @@ class Engine(object):
                                                    m.orig_x, m.orig_y, m.orig_c, m.orig_s))
         self.map = m
 
+    def set_map_occupancy(self, free, resolution, orig_x, orig_y, orig_theta=0.0):
+        """Map from an occupancy mask (nonzero = free, row 0 = bottom row, as after laser_models.py:399-404).
+        A CUDA uint8 tensor stays on the device: EDT, cell codes, LUT and the fp64 table are built there (~1 ms),
+        so a generated track can be installed every episode."""
+        import torch
+        oc, os_ = float(np.cos(orig_theta)), float(np.sin(orig_theta))
+        if torch.is_tensor(free) and free.is_cuda:
+            f = free.to(torch.uint8).contiguous()
+            if not bool((f == 0).any()):
+                raise ValueError('map has no occupied cell')
+            H, W = f.shape
+            _lib.check(self.lib.f110_set_map_occupancy_dev(self._h, f.data_ptr(), H, W, float(resolution), float(orig_x),
+                                                           float(orig_y), oc, os_))
+        else:
+            f = np.ascontiguousarray(np.asarray(free) != 0, dtype=np.uint8)
+            H, W = f.shape
+            _lib.check(self.lib.f110_set_map_occupancy(self._h, _np_ptr(f), H, W, float(resolution), float(orig_x),
+                                                       float(orig_y), oc, os_))
+        self.map = ('dt', (H, W))
+
     def set_map_dt(self, dt, resolution, orig_x, orig_y, orig_c=1.0, orig_s=0.0):
         dt = np.ascontiguousarray(dt, dtype=np.float64)
         _lib.check(self.lib.f110_set_map_dt(self._h, _np_ptr(dt), dt.shape[0], dt.shape[1], float(resolution),

@@ -151,6 +151,11 @@ class F110VecEnv(object):
     def update_map(self, map_path, map_ext):
         self.eng.set_map(map_path, map_ext)
 
+    def update_map_occupancy(self, free, resolution, orig_x, orig_y, orig_theta=0.0):
+        """Installs a map given as an occupancy mask (NumPy array or CUDA uint8 tensor, nonzero = free, row 0 at the
+        bottom); with a device tensor nothing but two scalars leaves the GPU."""
+        self.eng.set_map_occupancy(free, resolution, orig_x, orig_y, orig_theta)
+
     @property
     def state(self):
         return self.eng.t['state']

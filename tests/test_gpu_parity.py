@@ -218,3 +218,81 @@ def test_scan_rays_leaving_through_every_border(eng, ex_oracle):
     ref, rlk = ex_oracle.scan_batch(poses, return_lookups=True)
     out, lk = eng.scan(poses, want_lookups=True)
     assert np.array_equal(_np(out), ref) and np.array_equal(_np(lk).astype(np.int64), rlk)
+
+
+# ---- map pipeline on the device: exact EDT and the tables built from it
+def _edt_host(mask):
+    import ctypes as C
+    from red_gym_amd import _lib
+    H, W = mask.shape
+    d2 = np.empty((H, W), np.uint32)
+    _lib.check(_lib.load().f110_edt_squared(mask.ctypes.data_as(C.c_void_p), H, W, d2.ctypes.data_as(C.c_void_p)))
+    return d2
+
+
+def _edt_dev(mask):
+    import torch
+    from red_gym_amd import _lib
+    H, W = mask.shape
+    m = torch.as_tensor(mask, device='cuda')
+    d2 = torch.empty((H, W), dtype=torch.int32, device='cuda')
+    _lib.check(_lib.load().f110_edt_squared_dev(m.data_ptr(), H, W, d2.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    return d2.cpu().numpy().view(np.uint32)
+
+
+@pytest.mark.parametrize('shape,density', [((64, 64), 0.02), ((37, 201), 0.005), ((301, 17), 0.1), ((1, 50), 0.1),
+                                           ((50, 1), 0.1), ((257, 513), 0.0003), ((600, 600), 0.5), ((128, 4100), 0.001)])
+def test_edt_device_matches_host_and_scipy(shape, density):
+    from scipy.ndimage import distance_transform_edt
+    rng = np.random.default_rng(shape[0] * 1000 + shape[1])
+    mask = (rng.random(shape) >= density).astype(np.uint8)
+    mask[rng.integers(shape[0]), rng.integers(shape[1])] = 0         # at least one occupied cell
+    if shape[1] > 8:
+        mask[:, 3] = 1                                               # a column without any occupied cell
+    got = _edt_dev(mask)
+    assert np.array_equal(got, _edt_host(mask))
+    assert np.array_equal(got, np.rint(distance_transform_edt(mask) ** 2).astype(np.uint32))
+
+
+def test_edt_device_single_obstacle_and_full_maps():
+    mask = np.ones((200, 300), np.uint8)
+    mask[150, 20] = 0
+    yy, xx = np.mgrid[0:200, 0:300]
+    assert np.array_equal(_edt_dev(mask), ((yy - 150) ** 2 + (xx - 20) ** 2).astype(np.uint32))
+    assert not _edt_dev(np.zeros((40, 40), np.uint8)).any()
+
+
+def test_device_map_pipeline_equals_reference_distance_table():
+    """set_map through the device pipeline: the fp64 table equals the reference's resolution * scipy EDT
+    (laser_models.py:40-53) on every shipped map; maps of different sizes replace each other on one handle."""
+    from scipy.ndimage import distance_transform_edt
+    from red_gym_amd import F110VecEnv, workload, maps
+    env = F110VecEnv(4, map=workload.EXAMPLE_MAP, num_agents=1)
+    for name in ['berlin', 'vegas', 'skirk']:
+        y = maps.builtin_map_yaml(name)
+        m = maps.load_map(y, '.png')
+        env.update_map(y, '.png')
+        want = m.resolution * distance_transform_edt(m.free)
+        assert np.array_equal(env.eng.get_map_dt(), want), name
+    m = maps.load_map(workload.EXAMPLE_MAP + '.yaml', '.png')
+    env.update_map(workload.EXAMPLE_MAP + '.yaml', '.png')
+    assert np.array_equal(env.eng.get_map_dt(), m.resolution * distance_transform_edt(m.free))
+    env.close()
+
+
+def test_device_mask_map_matches_file_map_scans():
+    """A mask handed over as a CUDA tensor builds the same map as the file loader: identical scans."""
+    import torch
+    from red_gym_amd import F110VecEnv, workload, maps
+    m = maps.load_map(workload.EXAMPLE_MAP + '.yaml', '.png')
+    a = F110VecEnv(64, map=workload.EXAMPLE_MAP, num_agents=1)
+    b = F110VecEnv(64, map='berlin', num_agents=1)
+    b.update_map_occupancy(torch.as_tensor(m.free, device='cuda'), m.resolution, m.orig_x, m.orig_y,
+                           float(np.arctan2(m.orig_s, m.orig_c)))
+    poses = workload.spawn_poses(64, 1)
+    oa, ob = a.reset(poses)[0], b.reset(poses)[0]
+    assert torch.equal(oa['scans'], ob['scans'])
+    assert np.array_equal(a.eng.get_map_dt(), b.eng.get_map_dt())
+    with pytest.raises(ValueError):
+        b.update_map_occupancy(torch.ones((32, 32), dtype=torch.uint8, device='cuda'), 0.05, 0., 0.)
+    a.close(); b.close()
