@@ -124,6 +124,12 @@ int f110_set_map_occupancy(f110_handle *h, const uint8_t *free_mask_host, int32_
  * the host.  An all-free mask (no occupied cell) is the caller's responsibility here. */
 int f110_set_map_occupancy_dev(f110_handle *h, const uint8_t *free_mask_dev, int32_t height, int32_t width,
                                double resolution, double orig_x, double orig_y, double orig_c, double orig_s);
+/* Walls of a generated track (replaces the drawing half of unittest/random_trackgen.py:161-218): mask_dev
+ * [H*W] gets 0 where the distance from the pixel centre (x0 + (ix+.5)*pixel, y0 + (iy+.5)*pixel) to the
+ * polyline pts_dev [n_pts,2] (closed: last point joins the first) is within half_stroke of `offset`, else 1.
+ * Feed the result to f110_set_map_occupancy_dev. */
+int f110_track_mask(const double *pts_dev, int32_t n_pts, int32_t closed, int32_t height, int32_t width, double x0,
+                    double y0, double pixel, double offset, double half_stroke, uint8_t *mask_dev, void *stream);
 /* Same, from a precomputed distance table dt = resolution*edt(img) (host, [H*W] fp64). */
 int f110_set_map_dt(f110_handle *h, const double *dt_host, int32_t height, int32_t width,
                     double resolution, double orig_x, double orig_y, double orig_c, double orig_s);

@@ -52,6 +52,7 @@ SYMBOLS = {
     'f110_set_tables': [_VP, _VP, _VP, _VP, _VP, _VP],
     'f110_set_map_occupancy': [_VP, _VP, _I32, _I32, _D, _D, _D, _D, _D],
     'f110_set_map_occupancy_dev': [_VP, _VP, _I32, _I32, _D, _D, _D, _D, _D],
+    'f110_track_mask': [_VP, _I32, _I32, _I32, _I32, _D, _D, _D, _D, _D, _VP, _VP],
     'f110_set_map_dt': [_VP, _VP, _I32, _I32, _D, _D, _D, _D, _D],
     'f110_get_map_dt': [_VP, _VP],
     'f110_edt_squared': [_VP, _I32, _I32, _VP],

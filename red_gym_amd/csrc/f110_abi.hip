@@ -528,6 +528,18 @@ static int install_map_occupancy_dev(f110_handle *h, const uint8_t *mask_dev, in
 }
 
 
+extern "C" int f110_track_mask(const double *pts_dev, int32_t n_pts, int32_t closed, int32_t H, int32_t W, double x0, double y0,
+                               double pixel, double offset, double half_stroke, uint8_t *mask_dev, void *stream)
+{
+    if (!pts_dev || !mask_dev) return fail(F110_E_INVALID, "f110_track_mask: null pointer");
+    if (n_pts < 2 || H < 1 || W < 1 || H > 32768 || W > 32768 || !(pixel > 0) || !(half_stroke >= 0))
+        return fail(F110_E_INVALID, "f110_track_mask: bad arguments (n_pts=%d, %dx%d, pixel=%g)", n_pts, H, W, pixel);
+    hipLaunchKernelGGL(track_mask_kernel, dim3((W + 15) / 16, (H + 15) / 16), dim3(256), 0, (hipStream_t)stream, pts_dev, n_pts,
+                       closed ? 1 : 0, H, W, x0, y0, pixel, offset, half_stroke, mask_dev);
+    HIP_TRY(hipGetLastError());
+    return F110_OK;
+}
+
 static int check_map_args(f110_handle *h, const void *p, int H, int W, double res, const char *who)
 {
     if (!h || !p) return fail(F110_E_INVALID, "%s: null argument", who);

@@ -185,4 +185,48 @@ __global__ __launch_bounds__(256) void map_lut_kernel(const unsigned *bits, int 
     }
 }
 
+
+// ---- track walls from a centre line (red_gym_amd/trackgen.py): pixel (ix, iy) is a wall (0) iff the
+// distance of its centre to the polyline is within half_stroke of `offset`, free (1) otherwise.  The reference
+// strokes the two shapely offset curves with matplotlib (random_trackgen.py:161-193); the curves at distance
+// `offset` from a closed line are exactly that level set, drawn here without a geometry library.
+// One lane per pixel, the segments staged through LDS in chunks; fp64, plain mul/add.
+struct TrackSeg { double ax, ay, ex, ey, inv_l2; };
+constexpr int TRACK_CHUNK = 256;
+
+__global__ __launch_bounds__(256) void track_mask_kernel(const double *pts, int n_pts, int closed, int H, int W, double x0,
+                                                         double y0, double pixel, double offset, double half_stroke,
+                                                         uint8_t *mask)
+{
+    __shared__ TrackSeg s_seg[TRACK_CHUNK];
+    const int ix = blockIdx.x * 16 + (threadIdx.x & 15), iy = blockIdx.y * 16 + (threadIdx.x >> 4);
+    const double px = x0 + ((double)ix + 0.5) * pixel, py = y0 + ((double)iy + 0.5) * pixel;
+    const int n_seg = closed ? n_pts : n_pts - 1;
+    double best = __builtin_inf();
+    for (int base = 0; base < n_seg; base += TRACK_CHUNK) {
+        const int m = min(TRACK_CHUNK, n_seg - base);
+        __syncthreads();
+        if ((int)threadIdx.x < m) {
+            const int i = base + threadIdx.x, j = (i + 1) % n_pts;
+            TrackSeg sg;
+            sg.ax = pts[2 * i]; sg.ay = pts[2 * i + 1];
+            sg.ex = pts[2 * j] - sg.ax; sg.ey = pts[2 * j + 1] - sg.ay;
+            const double l2 = sg.ex * sg.ex + sg.ey * sg.ey;
+            sg.inv_l2 = l2 > 0.0 ? 1.0 / l2 : 0.0;
+            s_seg[threadIdx.x] = sg;
+        }
+        __syncthreads();
+        for (int k = 0; k < m; k++) {
+            const TrackSeg sg = s_seg[k];
+            const double rx = px - sg.ax, ry = py - sg.ay;
+            double t = (rx * sg.ex + ry * sg.ey) * sg.inv_l2;
+            t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
+            const double dx = rx - t * sg.ex, dy = ry - t * sg.ey;
+            const double d2 = dx * dx + dy * dy;
+            best = d2 < best ? d2 : best;
+        }
+    }
+    if (ix < W && iy < H) mask[(size_t)iy * W + ix] = fabs(sqrt(best) - offset) <= half_stroke ? 0 : 1;
+}
+
 } // namespace f110

@@ -156,6 +156,15 @@ class F110VecEnv(object):
         bottom); with a device tensor nothing but two scalars leaves the GPU."""
         self.eng.set_map_occupancy(free, resolution, orig_x, orig_y, orig_theta)
 
+    def randomize_track(self, seed):
+        """Domain randomisation: draws a random closed track (red_gym_amd.trackgen, the reference's
+        unittest/random_trackgen.py) on the GPU, installs it as the map of every env of this shard and returns the
+        Track (centre-line waypoints [N,3] = x, y, heading in world metres; waypoint 0 is the world origin)."""
+        from . import trackgen
+        t = trackgen.generate(seed, device=self.device)
+        self.eng.set_map_occupancy(t.free, t.resolution, t.orig_x, t.orig_y, 0.0)
+        return t
+
     @property
     def state(self):
         return self.eng.t['state']

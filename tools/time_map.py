@@ -22,3 +22,13 @@ for name in ['example_map', 'berlin', 'skirk', 'vegas']:
             env.update_map_occupancy(arg, m.resolution, m.orig_x, m.orig_y, th)
         torch.cuda.synchronize()
         print('%-12s %4dx%-4d %-11s %.2f ms per install' % (name, m.height, m.width, label, (time.perf_counter() - t0) / 5 * 1e3))
+
+for seed in (123, 7):
+    env.randomize_track(seed)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(5):
+        env.randomize_track(seed + k)
+    torch.cuda.synchronize()
+    print('random track (centre line on the host, walls + EDT + tables on the GPU): %.2f ms per track'
+          % ((time.perf_counter() - t0) / 5 * 1e3))
