@@ -38,6 +38,7 @@ extern "C" {
 #define F110_E_UNBOUND (-5)  /* step/reset before f110_bind */
 
 #define F110_MAX_AGENTS 8
+#define F110_MAX_MAPS 64  /* map slots of one handle (f110_set_map_slot_*, f110_assign_maps) */
 #define F110_NUM_PARAMS 18
 #define F110_RK4 1   /* Integrator.RK4   base_classes.py:40-42 */
 #define F110_EULER 2 /* Integrator.Euler */
@@ -130,6 +131,19 @@ int f110_set_map_occupancy_dev(f110_handle *h, const uint8_t *free_mask_dev, int
  * Feed the result to f110_set_map_occupancy_dev. */
 int f110_track_mask(const double *pts_dev, int32_t n_pts, int32_t closed, int32_t height, int32_t width, double x0,
                     double y0, double pixel, double offset, double half_stroke, uint8_t *mask_dev, void *stream);
+/* Map slots: one handle stands in for many F110Env instances, each of which may have its own map
+ * (f110_env.py:100-157 takes `map` per env).  Slot 0 is the map of the calls above; f110_set_map_slot_* fill
+ * slots 0..F110_MAX_MAPS-1 the same way, and f110_assign_maps gives every env its slot (host int32 [num_envs],
+ * NULL = all envs on slot 0).  The cars of one scan workgroup (2 consecutive cars) must share a map, i.e.
+ * assign maps to blocks of envs with an even car count; all slots in use should agree on "resolution is a
+ * power of two" and "origin unrotated", otherwise the general (slower) scan instantiation runs for all. */
+int f110_set_map_slot_occupancy(f110_handle *h, int32_t slot, const uint8_t *free_mask_host, int32_t height, int32_t width,
+                                double resolution, double orig_x, double orig_y, double orig_c, double orig_s);
+int f110_set_map_slot_occupancy_dev(f110_handle *h, int32_t slot, const uint8_t *free_mask_dev, int32_t height,
+                                    int32_t width, double resolution, double orig_x, double orig_y, double orig_c,
+                                    double orig_s);
+int f110_assign_maps(f110_handle *h, const int32_t *map_of_env_host);
+int f110_get_map_slot_dt(f110_handle *h, int32_t slot, double *dt_host_out);
 /* Same, from a precomputed distance table dt = resolution*edt(img) (host, [H*W] fp64). */
 int f110_set_map_dt(f110_handle *h, const double *dt_host, int32_t height, int32_t width,
                     double resolution, double orig_x, double orig_y, double orig_c, double orig_s);

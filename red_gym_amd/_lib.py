@@ -52,6 +52,10 @@ SYMBOLS = {
     'f110_set_tables': [_VP, _VP, _VP, _VP, _VP, _VP],
     'f110_set_map_occupancy': [_VP, _VP, _I32, _I32, _D, _D, _D, _D, _D],
     'f110_set_map_occupancy_dev': [_VP, _VP, _I32, _I32, _D, _D, _D, _D, _D],
+    'f110_set_map_slot_occupancy': [_VP, _I32, _VP, _I32, _I32, _D, _D, _D, _D, _D],
+    'f110_set_map_slot_occupancy_dev': [_VP, _I32, _VP, _I32, _I32, _D, _D, _D, _D, _D],
+    'f110_assign_maps': [_VP, _VP],
+    'f110_get_map_slot_dt': [_VP, _I32, _VP],
     'f110_track_mask': [_VP, _I32, _I32, _I32, _I32, _D, _D, _D, _D, _D, _VP, _VP],
     'f110_set_map_dt': [_VP, _VP, _I32, _I32, _D, _D, _D, _D, _D],
     'f110_get_map_dt': [_VP, _VP],

@@ -48,17 +48,28 @@ struct f110_handle {
     f110_buffers bufs;
     // device tables owned by the handle
     double *d_scan_angles = nullptr, *d_beam_cosines = nullptr, *d_side = nullptr;
-    uint16_t *d_cells = nullptr, *d_cells_far = nullptr, *d_chunk0 = nullptr;
+    uint16_t *d_chunk0 = nullptr;
     double2 *d_cs = nullptr;          // interleaved {cos, sin} LUT (repeated, see upload_cs)
     int cs_len = 0;
     double2 *d_beam_cs = nullptr;     // {cos, sin}(scan_angles) for the opponent ray cast
     std::vector<double> h_sines, h_cosines;
-    double *d_lut = nullptr, *d_lut_lds = nullptr, *d_dt = nullptr;
     double2 *d_noise_side = nullptr;  // [max(T,1), nb] {noise, side distance}
     long long noise_T = 0;
     std::vector<double> h_noise, h_side; // host copies the interleaved table is rebuilt from
-    MapDev map;
-    bool ident = false, pow2 = false;
+    // Maps.  Slot 0 is "the" map of the reference's API; further slots let blocks of envs of one shard run on
+    // different maps (one handle standing in for many F110Env instances with their own map each).
+    struct MapSlot {
+        uint16_t *d_cells = nullptr, *d_cells_far = nullptr;
+        double *d_lut = nullptr, *d_lut_lds = nullptr, *d_dt = nullptr;
+        MapDev dev;                   // host copy of d_maps[slot]
+        bool used = false, ident = false, pow2 = false;
+    };
+    MapSlot slots[F110_MAX_MAPS];
+    MapDev *d_maps = nullptr;         // dev [F110_MAX_MAPS] descriptors read by scan_kernel
+    int32_t *d_env_map = nullptr;     // dev [B] slot of every env; only passed to the kernel when `multi`
+    std::vector<int32_t> h_env_map;   // host copy (all 0 until f110_assign_maps)
+    bool multi = false;
+    bool ident = false, pow2 = false; // AND over the used slots: selects the scan_kernel instantiation
     double theta_inc = 0;
     // measurement aid (f110_profile_begin/end)
     std::vector<hipEvent_t> prof_ev; // pairs: [2*i] before, [2*i+1] after the scan launch
@@ -262,7 +273,7 @@ extern "C" int f110_create(const f110_config *cfg, f110_handle **out)
     memcpy(h->params.v, cfg->params, sizeof(double) * P_COUNT);
     for (int i = 0; i < F110_MAX_AGENTS; i++) h->agent_params[i] = h->params;
     memset(&h->bufs, 0, sizeof(h->bufs));
-    memset(&h->map, 0, sizeof(h->map));
+    for (auto &sl : h->slots) memset(&sl.dev, 0, sizeof(sl.dev));
     // laser_models.py:367-368
     const double angle_increment = cfg->fov / (cfg->num_beams - 1);
     h->theta_inc = cfg->theta_dis * angle_increment / (2. * F110_PI);
@@ -288,9 +299,12 @@ extern "C" void f110_destroy(f110_handle *h)
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
     void *ptrs[] = {h->d_cs, h->d_beam_cs, h->d_noise_side, h->d_scan_angles, h->d_beam_cosines, h->d_side,
-                    h->d_cells, h->d_cells_far, h->d_lut, h->d_lut_lds, h->d_dt, h->d_chunk0, h->d_agent_params, h->d_opp_pairs};
+                    h->d_chunk0, h->d_agent_params, h->d_opp_pairs, h->d_maps, h->d_env_map};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    for (auto &sl : h->slots)
+        for (void *p : {(void *)sl.d_cells, (void *)sl.d_cells_far, (void *)sl.d_lut, (void *)sl.d_lut_lds, (void *)sl.d_dt})
+            if (p) (void)hipFree(p);
     for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
     delete h;
 }
@@ -334,30 +348,41 @@ extern "C" int f110_set_tables(f110_handle *h, const double *sines, const double
     return rc;
 }
 
-// Publishes the device tables of a freshly built map in the handle (both pipelines end here).
-static int finish_map(f110_handle *h, int H, int W, int Hp, size_t n_tiled, double res, double ox, double oy, double oc,
+// Publishes the device tables of a freshly built map in slot `slot` (both pipelines end here).
+static int finish_map(f110_handle *h, int slot, int H, int W, int Hp, size_t n_tiled, double res, double ox, double oy, double oc,
                       double os, double oob)
 {
-    MapDev &m = h->map;
-    m.cells = h->d_cells; m.cells_far = h->d_cells_far; m.lut = h->d_lut; m.lut_lds = h->d_lut_lds; m.dt = h->d_dt;
+    f110_handle::MapSlot &sl = h->slots[slot];
+    MapDev &m = sl.dev;
+    m.cells = sl.d_cells; m.cells_far = sl.d_cells_far; m.lut = sl.d_lut; m.lut_lds = sl.d_lut_lds; m.dt = sl.d_dt;
     m.H = H; m.W = W; m.strip_bytes = (unsigned)Hp * 16u; m.cells_bytes = (unsigned)(n_tiled * sizeof(uint16_t)); m.res = res; m.rinv = 1.0 / res;
     m.ox = ox; m.oy = oy; m.oc = oc; m.os = os;
     m.wres = W * res; // width * resolution (laser_models.py:79)
     m.hres = H * res;
     m.oob = oob;      // dt[-1, -1]
     int e = 0;
-    h->pow2 = std::frexp(res, &e) == 0.5;
-    h->ident = (oc == 1.0 && os == 0.0);
-    h->has_map = true;
+    sl.pow2 = std::frexp(res, &e) == 0.5;
+    sl.ident = (oc == 1.0 && os == 0.0);
+    sl.used = true;
+    if (!h->d_maps) {
+        HIP_TRY(hipMalloc((void **)&h->d_maps, sizeof(MapDev) * F110_MAX_MAPS));
+        HIP_TRY(hipMemset(h->d_maps, 0, sizeof(MapDev) * F110_MAX_MAPS));
+    }
+    HIP_TRY(hipMemcpy(h->d_maps + slot, &m, sizeof(MapDev), hipMemcpyHostToDevice));
+    h->ident = h->pow2 = true;
+    for (const auto &u : h->slots)
+        if (u.used) { h->ident = h->ident && u.ident; h->pow2 = h->pow2 && u.pow2; }
+    h->has_map = h->slots[0].used;
     return F110_OK;
 }
 
 // Builds the device map from a host fp64 distance table (and, when known, its
 // exact squared form).  Cells whose value is not resolution*sqrt(integer) keep
 // the escape code and are served from the fp64 table.
-static int install_map(f110_handle *h, const double *dt, const uint32_t *d2_or_null, int H, int W, double res,
+static int install_map(f110_handle *h, int slot, const double *dt, const uint32_t *d2_or_null, int H, int W, double res,
                        double ox, double oy, double oc, double os)
 {
+    f110_handle::MapSlot &sl = h->slots[slot];
     const size_t n = (size_t)H * W;
     // padded table (one border cell on every side), 8-column strips: see MapDev
     const int strips = (W + 2 + 7) >> 3, Hp = ((H + 2 + 7) >> 3) << 3;
@@ -398,24 +423,25 @@ static int install_map(f110_handle *h, const double *dt, const uint32_t *d2_or_n
     }
     HIP_TRY(hipSetDevice(h->cfg.device));
     HIP_TRY(hipDeviceSynchronize()); // the previous map may still be in use by enqueued steps
-    if (h->d_cells) { (void)hipFree(h->d_cells); h->d_cells = nullptr; }
-    if (h->d_cells_far) { (void)hipFree(h->d_cells_far); h->d_cells_far = nullptr; }
-    if (h->d_dt) { (void)hipFree(h->d_dt); h->d_dt = nullptr; }
-    if (h->d_lut) { (void)hipFree(h->d_lut); h->d_lut = nullptr; } // its length depends on the map
-    h->has_map = false;
-    HIP_TRY(hipMalloc((void **)&h->d_cells, n_tiled * sizeof(uint16_t)));
-    HIP_TRY(hipMalloc((void **)&h->d_dt, n * sizeof(double)));
-    HIP_TRY(hipMemcpy(h->d_cells, cells.data(), n_tiled * sizeof(uint16_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMalloc((void **)&h->d_cells_far, n_tiled * sizeof(uint16_t)));
-    HIP_TRY(hipMemcpy(h->d_cells_far, cells_far.data(), n_tiled * sizeof(uint16_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(h->d_dt, dt, n * sizeof(double), hipMemcpyHostToDevice));
-    int rc = upload(&h->d_lut, lut.data(), lut.size());
+    if (sl.d_cells) { (void)hipFree(sl.d_cells); sl.d_cells = nullptr; }
+    if (sl.d_cells_far) { (void)hipFree(sl.d_cells_far); sl.d_cells_far = nullptr; }
+    if (sl.d_dt) { (void)hipFree(sl.d_dt); sl.d_dt = nullptr; }
+    if (sl.d_lut) { (void)hipFree(sl.d_lut); sl.d_lut = nullptr; } // its length depends on the map
+    sl.used = false;
+    h->has_map = h->slots[0].used;
+    HIP_TRY(hipMalloc((void **)&sl.d_cells, n_tiled * sizeof(uint16_t)));
+    HIP_TRY(hipMalloc((void **)&sl.d_dt, n * sizeof(double)));
+    HIP_TRY(hipMemcpy(sl.d_cells, cells.data(), n_tiled * sizeof(uint16_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc((void **)&sl.d_cells_far, n_tiled * sizeof(uint16_t)));
+    HIP_TRY(hipMemcpy(sl.d_cells_far, cells_far.data(), n_tiled * sizeof(uint16_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(sl.d_dt, dt, n * sizeof(double), hipMemcpyHostToDevice));
+    int rc = upload(&sl.d_lut, lut.data(), lut.size());
     if (rc) return rc;
     std::vector<double> lut_lds(lut.begin(), lut.begin() + LUT_LDS);
     lut_lds[SLOT_FAR] = 0.0;          // never used as a distance (OFF_FAR cells take the second table)
     lut_lds[SLOT_BORDER] = dt[n - 1]; // dt[-1, -1]
-    if ((rc = upload(&h->d_lut_lds, lut_lds.data(), lut_lds.size()))) return rc;
-    return finish_map(h, H, W, Hp, n_tiled, res, ox, oy, oc, os, dt[n - 1]);
+    if ((rc = upload(&sl.d_lut_lds, lut_lds.data(), lut_lds.size()))) return rc;
+    return finish_map(h, slot, H, W, Hp, n_tiled, res, ox, oy, oc, os, dt[n - 1]);
 }
 
 // ---------------------------------------------------------------- map pipeline on the device
@@ -468,9 +494,10 @@ extern "C" int f110_edt_squared_dev(const uint8_t *mask_dev, int32_t H, int32_t 
 }
 
 // Occupancy mask (device) -> all map tables, without leaving the GPU.  mask: nonzero = free.
-static int install_map_occupancy_dev(f110_handle *h, const uint8_t *mask_dev, int H, int W, double res, double ox, double oy,
-                                     double oc, double os)
+static int install_map_occupancy_dev(f110_handle *h, int slot, const uint8_t *mask_dev, int H, int W, double res, double ox,
+                                     double oy, double oc, double os)
 {
+    f110_handle::MapSlot &sl = h->slots[slot];
     const size_t n = (size_t)H * W;
     const int strips = (W + 2 + 7) >> 3, Hp = ((H + 2 + 7) >> 3) << 3;
     const size_t n_tiled = (size_t)strips * Hp * 8;
@@ -500,31 +527,32 @@ static int install_map_occupancy_dev(f110_handle *h, const uint8_t *mask_dev, in
     hipLaunchKernelGGL(rank_word_prefix_kernel, dim3(n_blocks), dim3(256), 0, st, bits, n_words, sums, prefix);
     HIP_TRY(hipGetLastError());
     // the handle's tables
-    if (h->d_cells) { (void)hipFree(h->d_cells); h->d_cells = nullptr; }
-    if (h->d_cells_far) { (void)hipFree(h->d_cells_far); h->d_cells_far = nullptr; }
-    if (h->d_dt) { (void)hipFree(h->d_dt); h->d_dt = nullptr; }
-    if (h->d_lut) { (void)hipFree(h->d_lut); h->d_lut = nullptr; }
-    h->has_map = false;
-    HIP_TRY(hipMalloc((void **)&h->d_cells, n_tiled * sizeof(uint16_t)));
-    HIP_TRY(hipMalloc((void **)&h->d_cells_far, n_tiled * sizeof(uint16_t)));
-    HIP_TRY(hipMalloc((void **)&h->d_dt, n * sizeof(double)));
+    if (sl.d_cells) { (void)hipFree(sl.d_cells); sl.d_cells = nullptr; }
+    if (sl.d_cells_far) { (void)hipFree(sl.d_cells_far); sl.d_cells_far = nullptr; }
+    if (sl.d_dt) { (void)hipFree(sl.d_dt); sl.d_dt = nullptr; }
+    if (sl.d_lut) { (void)hipFree(sl.d_lut); sl.d_lut = nullptr; }
+    sl.used = false;
+    h->has_map = h->slots[0].used;
+    HIP_TRY(hipMalloc((void **)&sl.d_cells, n_tiled * sizeof(uint16_t)));
+    HIP_TRY(hipMalloc((void **)&sl.d_cells_far, n_tiled * sizeof(uint16_t)));
+    HIP_TRY(hipMalloc((void **)&sl.d_dt, n * sizeof(double)));
     const unsigned n_lut = CODE_ESC; // ranks 0..65534 are encodable; unused slots stay 0.0
-    HIP_TRY(hipMalloc((void **)&h->d_lut, (size_t)n_lut * sizeof(double)));
-    HIP_TRY(hipMemsetAsync(h->d_lut, 0, (size_t)n_lut * sizeof(double), st));
-    hipLaunchKernelGGL(map_fill_border_kernel, dim3((unsigned)((n_tiled + 255) / 256)), dim3(256), 0, st, h->d_cells, h->d_cells_far, n_tiled);
-    hipLaunchKernelGGL(map_encode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d2, H, W, Hp, bits, prefix, res, h->d_cells,
-                       h->d_cells_far, h->d_dt);
-    hipLaunchKernelGGL(map_lut_kernel, dim3((n_words + 255) / 256), dim3(256), 0, st, bits, n_words, prefix, res, h->d_lut, n_lut);
+    HIP_TRY(hipMalloc((void **)&sl.d_lut, (size_t)n_lut * sizeof(double)));
+    HIP_TRY(hipMemsetAsync(sl.d_lut, 0, (size_t)n_lut * sizeof(double), st));
+    hipLaunchKernelGGL(map_fill_border_kernel, dim3((unsigned)((n_tiled + 255) / 256)), dim3(256), 0, st, sl.d_cells, sl.d_cells_far, n_tiled);
+    hipLaunchKernelGGL(map_encode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d2, H, W, Hp, bits, prefix, res, sl.d_cells,
+                       sl.d_cells_far, sl.d_dt);
+    hipLaunchKernelGGL(map_lut_kernel, dim3((n_words + 255) / 256), dim3(256), 0, st, bits, n_words, prefix, res, sl.d_lut, n_lut);
     HIP_TRY(hipGetLastError());
     // LDS image of the LUT: its first slots, with the two special ones (see MapDev)
     std::vector<double> lut_lds(LUT_LDS);
     double oob = 0;
-    HIP_TRY(hipMemcpy(lut_lds.data(), h->d_lut, LUT_LDS * sizeof(double), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(&oob, h->d_dt + (n - 1), sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(lut_lds.data(), sl.d_lut, LUT_LDS * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&oob, sl.d_dt + (n - 1), sizeof(double), hipMemcpyDeviceToHost));
     lut_lds[SLOT_FAR] = 0.0;
     lut_lds[SLOT_BORDER] = oob;
-    if ((rc = upload(&h->d_lut_lds, lut_lds.data(), lut_lds.size()))) return rc;
-    return finish_map(h, H, W, Hp, n_tiled, res, ox, oy, oc, os, oob);
+    if ((rc = upload(&sl.d_lut_lds, lut_lds.data(), lut_lds.size()))) return rc;
+    return finish_map(h, slot, H, W, Hp, n_tiled, res, ox, oy, oc, os, oob);
 }
 
 
@@ -548,11 +576,19 @@ static int check_map_args(f110_handle *h, const void *p, int H, int W, double re
     return F110_OK;
 }
 
-extern "C" int f110_set_map_occupancy(f110_handle *h, const uint8_t *mask, int32_t H, int32_t W, double res,
-                                      double ox, double oy, double oc, double os)
+static int check_slot(f110_handle *h, int slot, const char *who)
 {
-    int rc = check_map_args(h, mask, H, W, res, "f110_set_map_occupancy");
-    if (rc || (rc = check_edt_size(H, W, "f110_set_map_occupancy"))) return rc;
+    if (!h) return fail(F110_E_INVALID, "%s: null handle", who);
+    if (slot < 0 || slot >= F110_MAX_MAPS) return fail(F110_E_INDEX, "%s: map slot %d outside 0..%d", who, slot, F110_MAX_MAPS - 1);
+    return F110_OK;
+}
+
+extern "C" int f110_set_map_slot_occupancy(f110_handle *h, int32_t slot, const uint8_t *mask, int32_t H, int32_t W, double res,
+                                           double ox, double oy, double oc, double os)
+{
+    int rc = check_slot(h, slot, "f110_set_map_slot_occupancy");
+    if (rc || (rc = check_map_args(h, mask, H, W, res, "f110_set_map_occupancy")) || (rc = check_edt_size(H, W, "f110_set_map_occupancy")))
+        return rc;
     const size_t n = (size_t)H * W;
     if (!memchr(mask, 0, n)) return fail(F110_E_INVALID, "f110_set_map_occupancy: map has no occupied cell");
     HIP_TRY(hipSetDevice(h->cfg.device));
@@ -560,15 +596,29 @@ extern "C" int f110_set_map_occupancy(f110_handle *h, const uint8_t *mask, int32
     uint8_t *mask_dev = nullptr;
     HIP_TRY(tmp.alloc(&mask_dev, n));
     HIP_TRY(hipMemcpy(mask_dev, mask, n, hipMemcpyHostToDevice));
-    return install_map_occupancy_dev(h, mask_dev, H, W, res, ox, oy, oc, os);
+    return install_map_occupancy_dev(h, slot, mask_dev, H, W, res, ox, oy, oc, os);
+}
+
+extern "C" int f110_set_map_slot_occupancy_dev(f110_handle *h, int32_t slot, const uint8_t *mask_dev, int32_t H, int32_t W,
+                                               double res, double ox, double oy, double oc, double os)
+{
+    int rc = check_slot(h, slot, "f110_set_map_slot_occupancy_dev");
+    if (rc || (rc = check_map_args(h, mask_dev, H, W, res, "f110_set_map_occupancy_dev")) ||
+        (rc = check_edt_size(H, W, "f110_set_map_occupancy_dev")))
+        return rc;
+    return install_map_occupancy_dev(h, slot, mask_dev, H, W, res, ox, oy, oc, os);
+}
+
+extern "C" int f110_set_map_occupancy(f110_handle *h, const uint8_t *mask, int32_t H, int32_t W, double res,
+                                      double ox, double oy, double oc, double os)
+{
+    return f110_set_map_slot_occupancy(h, 0, mask, H, W, res, ox, oy, oc, os);
 }
 
 extern "C" int f110_set_map_occupancy_dev(f110_handle *h, const uint8_t *mask_dev, int32_t H, int32_t W, double res,
                                           double ox, double oy, double oc, double os)
 {
-    int rc = check_map_args(h, mask_dev, H, W, res, "f110_set_map_occupancy_dev");
-    if (rc || (rc = check_edt_size(H, W, "f110_set_map_occupancy_dev"))) return rc;
-    return install_map_occupancy_dev(h, mask_dev, H, W, res, ox, oy, oc, os);
+    return f110_set_map_slot_occupancy_dev(h, 0, mask_dev, H, W, res, ox, oy, oc, os);
 }
 
 extern "C" int f110_set_map_dt(f110_handle *h, const double *dt, int32_t H, int32_t W, double res, double ox,
@@ -576,15 +626,54 @@ extern "C" int f110_set_map_dt(f110_handle *h, const double *dt, int32_t H, int3
 {
     int rc = check_map_args(h, dt, H, W, res, "f110_set_map_dt");
     if (rc) return rc;
-    return install_map(h, dt, nullptr, H, W, res, ox, oy, oc, os);
+    return install_map(h, 0, dt, nullptr, H, W, res, ox, oy, oc, os);
 }
 
-extern "C" int f110_get_map_dt(f110_handle *h, double *out)
+extern "C" int f110_get_map_slot_dt(f110_handle *h, int32_t slot, double *out)
 {
-    if (!h || !out) return fail(F110_E_INVALID, "f110_get_map_dt: null argument");
-    if (!h->has_map) return fail(F110_E_NOMAP, "Map is not set for scan simulator.");
+    int rc = check_slot(h, slot, "f110_get_map_slot_dt");
+    if (rc) return rc;
+    if (!out) return fail(F110_E_INVALID, "f110_get_map_slot_dt: null argument");
+    const f110_handle::MapSlot &sl = h->slots[slot];
+    if (!sl.used) return fail(F110_E_NOMAP, "Map is not set for scan simulator.");
     HIP_TRY(hipSetDevice(h->cfg.device));
-    HIP_TRY(hipMemcpy(out, h->d_dt, (size_t)h->map.H * h->map.W * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, sl.d_dt, (size_t)sl.dev.H * sl.dev.W * sizeof(double), hipMemcpyDeviceToHost));
+    return F110_OK;
+}
+
+extern "C" int f110_get_map_dt(f110_handle *h, double *out) { return f110_get_map_slot_dt(h, 0, out); }
+
+// env -> map slot.  The cars of one scan workgroup (SCAN_WAVES consecutive cars) share the LDS copy of their
+// map's LUT, so they must be on the same map: with blocks of envs per map that holds whenever a block's car
+// count is a multiple of SCAN_WAVES.
+extern "C" int f110_assign_maps(f110_handle *h, const int32_t *map_of_env)
+{
+    if (!h) return fail(F110_E_INVALID, "f110_assign_maps: null handle");
+    const int B = h->cfg.num_envs, A = h->cfg.num_agents, N = B * A;
+    std::vector<int32_t> m(B, 0);
+    bool multi = false;
+    if (map_of_env)
+        for (int e = 0; e < B; e++) {
+            const int k = map_of_env[e];
+            if (k < 0 || k >= F110_MAX_MAPS || !h->slots[k].used)
+                return fail(F110_E_INDEX, "f110_assign_maps: env %d uses map slot %d, which holds no map", e, k);
+            m[e] = k;
+            multi = multi || k != 0;
+        }
+    if (multi) {
+        if (N % SCAN_WAVES) return fail(F110_E_INVALID, "f110_assign_maps: %d cars is not a multiple of %d", N, SCAN_WAVES);
+        for (int c = 0; c < N; c += SCAN_WAVES)
+            for (int j = 1; j < SCAN_WAVES; j++)
+                if (m[(c + j) / A] != m[c / A])
+                    return fail(F110_E_INVALID, "f110_assign_maps: cars %d and %d share a scan workgroup but not a map "
+                                "(give every map a block of envs whose car count is a multiple of %d)", c, c + j, SCAN_WAVES);
+    }
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    HIP_TRY(hipDeviceSynchronize()); // enqueued steps may still read the table
+    if (!h->d_env_map) HIP_TRY(hipMalloc((void **)&h->d_env_map, sizeof(int32_t) * B));
+    HIP_TRY(hipMemcpy(h->d_env_map, m.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice));
+    h->h_env_map = m;
+    h->multi = multi;
     return F110_OK;
 }
 
@@ -685,7 +774,9 @@ static int launch_scan(f110_handle *h, const ScanArgs &a_in, hipStream_t st)
     static const char *tail_env = getenv("F110_TAIL_CARS");
     int n_tail = 0;
     if (a.wpc == 1 && (a.scan.nb + 63) / 64 >= TAIL_WPC) n_tail = tail_env ? atoi(tail_env) : std::min(2048, a.n_cars / 2);
-    a.n_tail = std::max(0, std::min(n_tail, a.n_cars));
+    n_tail = std::max(0, std::min(n_tail, a.n_cars));
+    if (n_tail > 0 && ((a.n_cars - n_tail) % SCAN_WAVES)) n_tail = std::min(a.n_cars, n_tail + (a.n_cars - n_tail) % SCAN_WAVES); // a workgroup never mixes a whole car with a split one
+    a.n_tail = n_tail;
     return a.state ? launch_scan_t<true>(h, a, st) : launch_scan_t<false>(h, a, st);
 }
 
@@ -704,7 +795,7 @@ static int run_step(f110_handle *h, const double *actions, int reset_only, hipSt
 
     ScanArgs s;
     memset(&s, 0, sizeof(s));
-    s.map = h->map; s.scan = scan_dev(h); s.n_cars = N; s.agents = c.num_agents;
+    s.maps = h->d_maps; s.env_map = h->multi ? h->d_env_map : nullptr; s.scan = scan_dev(h); s.n_cars = N; s.agents = c.num_agents;
     s.pose_src = b.state; s.pose_stride = 7; s.yaw_off = 4;
     s.state = b.state; s.noise_step = b.noise_step; s.chunk_beam0 = h->d_chunk0;
     s.noise_side = h->d_noise_side; s.noise_T = h->noise_T > 0 ? h->noise_T : 1;
@@ -850,7 +941,7 @@ extern "C" int f110_scan(f110_handle *h, const double *poses, int32_t n, double 
     if (!poses || (!out64 && !out32)) return fail(F110_E_INVALID, "f110_scan: null pose or output pointer");
     ScanArgs s;
     memset(&s, 0, sizeof(s));
-    s.map = h->map; s.scan = scan_dev(h); s.n_cars = n; s.agents = 1;
+    s.maps = h->d_maps; s.scan = scan_dev(h); s.n_cars = n; s.agents = 1;
     s.pose_src = poses; s.pose_stride = 3; s.yaw_off = 2;
     s.out_f32 = out32; s.out_f64 = out64; s.lookups = lookups; s.noise_T = 1; s.chunk_beam0 = h->d_chunk0;
     return launch_scan(h, s, (hipStream_t)stream);

@@ -199,7 +199,9 @@ __device__ inline int beam_theta_index(unsigned long long T0, double t0w, int b,
 }
 
 struct ScanArgs {
-    MapDev map;
+    const MapDev *maps;         // dev [K] map descriptors
+    const int32_t *env_map;     // dev [B] map of every env, or NULL (all envs on maps[0]); the cars of one
+                                // workgroup share a map (f110_assign_maps checks it): its LUT is staged per group
     ScanDev scan;
     int n_cars;
     int agents;             // A (cars of one env are consecutive)
@@ -246,17 +248,6 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
     __shared__ __attribute__((aligned(16))) double s_lut[LUT_LDS];
     __shared__ int s_chunk0[MAX_CHUNKS];
     const int nb = a.scan.nb;
-    {   // LDS image of the LUT prepared by the host (slot SLOT_BORDER = dt[-1,-1]): 16-B copies
-        const double2 *src = reinterpret_cast<const double2 *>(a.map.lut_lds);
-        double2 *dst = reinterpret_cast<double2 *>(s_lut);
-        for (int i = threadIdx.x; i < LUT_LDS / 2; i += SCAN_THREADS) dst[i] = src[i];
-    }
-    for (int i = threadIdx.x; i < ((nb + 63) >> 6); i += SCAN_THREADS) s_chunk0[i] = a.chunk_beam0[i];
-    __syncthreads();
-    MapView mv;
-    mv.cells_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(a.map.cells), 0, (int)a.map.cells_bytes, 0x00020000);
-    mv.init(a.map);
-
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int wid = blockIdx.x * SCAN_WAVES + wave; // wave-uniform (scalar)
     // wave -> (car, part of its beam queue).  Kept to one extra argument and shifts: this kernel sits at
@@ -269,6 +260,19 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
     } else {
         car = wid / wpc; part = wid % wpc;
     }
+    // the car's map (wave-uniform: scalar loads); waves past the last car still help to stage the LUT
+    const int car_c = min(car, a.n_cars - 1);
+    const MapDev &md = a.maps[a.env_map ? a.env_map[car_c / a.agents] : 0];
+    {   // LDS image of the LUT prepared by the host (slot SLOT_BORDER = dt[-1,-1]): 16-B copies
+        const double2 *src = reinterpret_cast<const double2 *>(md.lut_lds);
+        double2 *dst = reinterpret_cast<double2 *>(s_lut);
+        for (int i = threadIdx.x; i < LUT_LDS / 2; i += SCAN_THREADS) dst[i] = src[i];
+    }
+    for (int i = threadIdx.x; i < ((nb + 63) >> 6); i += SCAN_THREADS) s_chunk0[i] = a.chunk_beam0[i];
+    __syncthreads();
+    MapView mv;
+    mv.cells_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(md.cells), 0, (int)md.cells_bytes, 0x00020000);
+    mv.init(md);
     if (car >= a.n_cars) return;
     // this wave's slice of the car's beam queue: chunk positions part, part+wpc, ...
     const int nch = (nb + 63) >> 6;

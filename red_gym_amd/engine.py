@@ -123,6 +123,7 @@ class Engine(object):
                                             _np_ptr(self.scan_angles), _np_ptr(self.beam_cosines),
                                             _np_ptr(self.side_distances)))
         self.map = None
+        self.slot_shapes = {}
         self.noise = None
         self._noise_dev_rows = 0
         self.host_steps_bound = 0
@@ -186,7 +187,7 @@ class Engine(object):
                                                    m.orig_x, m.orig_y, m.orig_c, m.orig_s))
         self.map = m
 
-    def set_map_occupancy(self, free, resolution, orig_x, orig_y, orig_theta=0.0):
+    def set_map_occupancy(self, free, resolution, orig_x, orig_y, orig_theta=0.0, slot=0):
         """Map from an occupancy mask (nonzero = free, row 0 = bottom row, as after laser_models.py:399-404).
         A CUDA uint8 tensor stays on the device: EDT, cell codes, LUT and the fp64 table are built there (~1 ms),
         so a generated track can be installed every episode."""
@@ -197,14 +198,27 @@ class Engine(object):
             if not bool((f == 0).any()):
                 raise ValueError('map has no occupied cell')
             H, W = f.shape
-            _lib.check(self.lib.f110_set_map_occupancy_dev(self._h, f.data_ptr(), H, W, float(resolution), float(orig_x),
-                                                           float(orig_y), oc, os_))
+            _lib.check(self.lib.f110_set_map_slot_occupancy_dev(self._h, int(slot), f.data_ptr(), H, W, float(resolution),
+                                                                float(orig_x), float(orig_y), oc, os_))
         else:
             f = np.ascontiguousarray(np.asarray(free) != 0, dtype=np.uint8)
             H, W = f.shape
-            _lib.check(self.lib.f110_set_map_occupancy(self._h, _np_ptr(f), H, W, float(resolution), float(orig_x),
-                                                       float(orig_y), oc, os_))
-        self.map = ('dt', (H, W))
+            _lib.check(self.lib.f110_set_map_slot_occupancy(self._h, int(slot), _np_ptr(f), H, W, float(resolution),
+                                                            float(orig_x), float(orig_y), oc, os_))
+        self.slot_shapes[int(slot)] = (H, W)
+        if slot == 0:
+            self.map = ('dt', (H, W))
+
+    def assign_maps(self, map_of_env=None):
+        """Gives every env its map slot (int array [num_envs]; None: all on slot 0).  Maps go to blocks of envs whose
+        car count is even (the two cars of a scan workgroup share a map); ValueError / IndexError otherwise."""
+        if map_of_env is None:
+            _lib.check(self.lib.f110_assign_maps(self._h, None))
+            return
+        m = np.ascontiguousarray(map_of_env, dtype=np.int32)
+        if m.shape != (self.B,):
+            raise ValueError('map_of_env must have one entry per env (%d), got shape %s' % (self.B, m.shape))
+        _lib.check(self.lib.f110_assign_maps(self._h, _np_ptr(m)))
 
     def set_map_dt(self, dt, resolution, orig_x, orig_y, orig_c=1.0, orig_s=0.0):
         dt = np.ascontiguousarray(dt, dtype=np.float64)
@@ -212,12 +226,17 @@ class Engine(object):
                                             float(orig_x), float(orig_y), float(orig_c), float(orig_s)))
         self.map = ('dt', dt.shape)
 
-    def get_map_dt(self):
-        if self.map is None:
-            raise ValueError('Map is not set for scan simulator.')
-        shape = (self.map.height, self.map.width) if not isinstance(self.map, tuple) else self.map[1]
+    def get_map_dt(self, slot=0):
+        if slot == 0:
+            if self.map is None:
+                raise ValueError('Map is not set for scan simulator.')
+            shape = (self.map.height, self.map.width) if not isinstance(self.map, tuple) else self.map[1]
+        else:
+            if slot not in self.slot_shapes:
+                raise ValueError('Map is not set for scan simulator.')
+            shape = self.slot_shapes[slot]
         out = np.empty(shape, dtype=np.float64)
-        _lib.check(self.lib.f110_get_map_dt(self._h, _np_ptr(out)))
+        _lib.check(self.lib.f110_get_map_slot_dt(self._h, int(slot), _np_ptr(out)))
         return out
 
     def update_params(self, params, agent_idx=-1):

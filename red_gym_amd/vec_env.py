@@ -165,6 +165,21 @@ class F110VecEnv(object):
         self.eng.set_map_occupancy(t.free, t.resolution, t.orig_x, t.orig_y, 0.0)
         return t
 
+    def randomize_tracks(self, seeds):
+        """One random track per seed, installed in map slots 0..K-1, with the envs split into K equal blocks (env e
+        drives on track e*K // num_envs) -- what K separate reference envs with their own `map` would be.  Returns
+        the Tracks and the int array [num_envs] of slots."""
+        from . import trackgen
+        seeds = list(seeds)
+        tracks = []
+        for k, seed in enumerate(seeds):
+            t = trackgen.generate(seed, device=self.device)
+            self.eng.set_map_occupancy(t.free, t.resolution, t.orig_x, t.orig_y, 0.0, slot=k)
+            tracks.append(t)
+        assign = (np.arange(self.num_envs) * len(seeds)) // self.num_envs
+        self.eng.assign_maps(assign)
+        return tracks, assign
+
     @property
     def state(self):
         return self.eng.t['state']

@@ -74,3 +74,63 @@ def test_generated_track_is_a_drivable_loop():
     t2 = env.randomize_track(seed=7)
     assert not torch.equal(t2.free, t.free)
     env.close()
+
+
+def test_map_slots_give_env_blocks_their_own_map():
+    """Blocks of envs on different maps inside one handle scan exactly like separate single-map envs on those maps."""
+    from red_gym_amd import F110VecEnv, workload, maps
+    B = 96
+    multi = F110VecEnv(B, map=workload.EXAMPLE_MAP, num_agents=1)
+    names = [None, 'berlin', 'skirk']
+    for k, name in enumerate(names):
+        y = workload.EXAMPLE_MAP + '.yaml' if name is None else maps.builtin_map_yaml(name)
+        m = maps.load_map(y, '.png')
+        multi.eng.set_map_occupancy(m.free, m.resolution, m.orig_x, m.orig_y, float(np.arctan2(m.orig_s, m.orig_c)), slot=k)
+    assign = (np.arange(B) * 3) // B
+    multi.eng.assign_maps(assign)
+    rng = np.random.default_rng(0)
+    poses = np.zeros((B, 1, 3))
+    poses[:, 0, :2] = rng.uniform(-3, 3, (B, 2))
+    poses[:, 0, 2] = rng.uniform(-3, 3, B)
+    acts = workload.action_pool(4, B, 1)
+    om = multi.reset(poses)[0]
+    singles = [F110VecEnv(B, map=(workload.EXAMPLE_MAP if n is None else n), num_agents=1) for n in names]
+    outs = [s.reset(poses)[0] for s in singles]
+    for step in range(4):
+        for k in range(3):
+            sel = torch.as_tensor(assign == k, device=multi.device)
+            assert torch.equal(om['scans'][sel], outs[k]['scans'][sel]), (step, k)
+            assert torch.equal(om['collisions'][sel], outs[k]['collisions'][sel])
+        om = multi.step(acts[step])[0]
+        outs = [s.step(acts[step])[0] for s in singles]
+    assert np.array_equal(multi.eng.get_map_dt(slot=1), singles[1].eng.get_map_dt())
+    # the maps differ, so the blocks really see different worlds
+    assert not torch.equal(outs[0]['scans'], outs[1]['scans'])
+    # error behaviour: unused slot, odd split of a workgroup
+    with pytest.raises(IndexError):
+        multi.eng.assign_maps(np.full(B, 5))
+    bad = np.zeros(B, dtype=np.int32); bad[1:] = 1
+    with pytest.raises(ValueError):
+        multi.eng.assign_maps(bad)
+    multi.eng.assign_maps(None)
+    assert torch.equal(multi.reset(poses)[0]['scans'], singles[0].reset(poses)[0]['scans'])
+    for e in [multi] + singles:
+        e.close()
+
+
+def test_randomize_tracks_blocks_drive_their_own_track():
+    from red_gym_amd import F110VecEnv, workload
+    B = 128
+    env = F110VecEnv(B, map=workload.EXAMPLE_MAP, num_agents=1, autoreset=False)
+    tracks, assign = env.randomize_tracks([11, 12, 13, 14])
+    assert len(tracks) == 4 and assign.tolist() == sorted(assign.tolist()) and set(assign) == {0, 1, 2, 3}
+    poses = np.zeros((B, 1, 3))
+    for e in range(B):
+        wp = tracks[assign[e]].waypoints
+        poses[e, 0] = wp[(e * 5) % len(wp)]
+    obs = env.reset(poses)[0]
+    assert not bool(obs['collisions'].any())
+    # on its own track a car sits mid-corridor: left/right beams see the walls ~1.7 m away (corners excepted)
+    side = obs['scans'][:, 0, [180, 900]]
+    assert float(side.min()) > 0.8 and 1.4 < float(side.median()) < 2.2 and float((side > 4.0).float().mean()) < 0.1
+    env.close()
