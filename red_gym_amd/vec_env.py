@@ -141,6 +141,22 @@ class F110VecEnv(object):
             waypoints = torch.as_tensor(np.ascontiguousarray(waypoints, dtype=np.float64), device=self.device)
         return self.eng.pure_pursuit(waypoints, lookahead, vgain, wheelbase)
 
+    def pure_pursuit_blocks(self, waypoint_sets, assign, lookahead, vgain, wheelbase=0.17145 + 0.15875):
+        """Pure-pursuit actions when blocks of envs drive on different tracks (randomize_tracks): waypoint_sets[k]
+        is the raceline [M_k,3] = (x, y, speed) of slot k, assign the int array [num_envs] of slots (blocks of
+        consecutive envs).  One planner launch per block, all into one [B,A,2] action tensor."""
+        if getattr(self, '_pp_actions', None) is None:
+            self._pp_actions = torch.empty((self.num_envs, self.num_agents, 2), dtype=torch.float64, device=self.device)
+        assign = np.asarray(assign)
+        bounds = np.flatnonzero(np.diff(assign)) + 1
+        for lo, hi in zip(np.r_[0, bounds], np.r_[bounds, self.num_envs]):
+            wp = waypoint_sets[int(assign[lo])]
+            if not torch.is_tensor(wp) or wp.device != self.device:
+                wp = torch.as_tensor(np.ascontiguousarray(wp, dtype=np.float64), device=self.device)
+            self.eng.pure_pursuit(wp, lookahead, vgain, wheelbase, state=self.eng.t['state'][lo:hi],
+                                  out=self._pp_actions[lo:hi].view(-1, 2))
+        return self._pp_actions
+
     def update_params(self, params, index=-1):
         """base_classes.py:507-527: index < 0 updates every agent, otherwise agent `index` of
         every env; IndexError beyond the agent list."""

@@ -133,4 +133,13 @@ def test_randomize_tracks_blocks_drive_their_own_track():
     # on its own track a car sits mid-corridor: left/right beams see the walls ~1.7 m away (corners excepted)
     side = obs['scans'][:, 0, [180, 900]]
     assert float(side.min()) > 0.8 and 1.4 < float(side.median()) < 2.2 and float((side > 4.0).float().mean()) < 0.1
+    # closed loop on four tracks at once: one planner launch per block of envs
+    wps = [torch.as_tensor(np.column_stack([t.waypoints[:, :2], np.full(len(t.waypoints), 3.0)]), device=env.device) for t in tracks]
+    crashed = torch.zeros(B, dtype=torch.bool, device=env.device)
+    for _ in range(300):
+        obs = env.step(env.pure_pursuit_blocks(wps, assign, 1.5, 1.0))[0]
+        crashed |= obs['collisions'][:, 0] > 0
+    assert int(crashed.sum()) == 0
+    moved = torch.linalg.norm(env.state[:, 0, :2] - torch.as_tensor(poses[:, 0, :2], device=env.device), dim=1)
+    assert float(moved.median()) > 4.0
     env.close()
