@@ -814,10 +814,10 @@ static int run_step(f110_handle *h, const double *actions, int reset_only, hipSt
         o.in_collision = b.in_collision; o.scan_angles = h->d_scan_angles; o.beam_cs = h->d_beam_cs; o.agent_params = h->d_agent_params;
         o.pending_reset = b.pending_reset; o.reset_only = reset_only; o.scans32 = b.scans; o.scans64 = b.scans_f64;
         o.pairs = h->d_opp_pairs;
-        const int npairs = N * (c.num_agents - 1), wpcar = (c.num_beams + 63) / 64;
+        const int npairs = N * (c.num_agents - 1);
         hipLaunchKernelGGL(opp_setup_kernel, dim3((npairs + 127) / 128), dim3(128), 0, st, o);
         HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(opp_apply_kernel, dim3((N * wpcar + 3) / 4), dim3(256), 0, st, o);
+        hipLaunchKernelGGL(opp_apply_kernel, dim3((N + 3) / 4), dim3(256), 0, st, o);
         HIP_TRY(hipGetLastError());
     }
 
