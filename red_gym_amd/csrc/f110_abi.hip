@@ -385,7 +385,7 @@ static int install_map(f110_handle *h, int slot, const double *dt, const uint32_
     f110_handle::MapSlot &sl = h->slots[slot];
     const size_t n = (size_t)H * W;
     // padded table (one border cell on every side), 8-column strips: see MapDev
-    const int strips = (W + 2 + 7) >> 3, Hp = ((H + 2 + 7) >> 3) << 3;
+    const int strips = (W >> 3) + 2, Hp = ((H + 2 + 7) >> 3) << 3; // strip 0 only holds the left border column
     const size_t n_tiled = (size_t)strips * Hp * 8;
     std::vector<uint16_t> cells(n_tiled, (uint16_t)OFF_BORDER), cells_far(n_tiled, 0);
     // exact squared distance of every cell (ESC64: not of the form resolution*sqrt(integer))
@@ -414,8 +414,8 @@ static int install_map(f110_handle *h, int slot, const double *dt, const uint32_
     std::vector<double> lut(n_lut, 0.0);
     for (size_t k = 0; k < n_lut && k < distinct.size(); k++) lut[k] = res * std::sqrt((double)distinct[k]);
     for (size_t i = 0; i < n; i++) {
-        const size_t r = i / W + 1, c = i % W + 1;
-        const size_t t = ((c >> 3) * (size_t)Hp + r) * 8 + (c & 7);
+        const size_t r = i / W + 1, c = i % W;
+        const size_t t = (((c >> 3) + 1) * (size_t)Hp + r) * 8 + (c & 7);
         size_t rank = CODE_ESC;
         if (d2v[i] != ESC64) rank = std::min<size_t>(std::lower_bound(distinct.begin(), distinct.end(), d2v[i]) - distinct.begin(), CODE_ESC);
         cells[t] = (uint16_t)(rank < SLOT_FAR ? 8 * rank : OFF_FAR);
@@ -499,7 +499,7 @@ static int install_map_occupancy_dev(f110_handle *h, int slot, const uint8_t *ma
 {
     f110_handle::MapSlot &sl = h->slots[slot];
     const size_t n = (size_t)H * W;
-    const int strips = (W + 2 + 7) >> 3, Hp = ((H + 2 + 7) >> 3) << 3;
+    const int strips = (W >> 3) + 2, Hp = ((H + 2 + 7) >> 3) << 3; // strip 0 only holds the left border column
     const size_t n_tiled = (size_t)strips * Hp * 8;
     HIP_TRY(hipSetDevice(h->cfg.device));
     HIP_TRY(hipDeviceSynchronize()); // the previous map may still be in use by enqueued steps

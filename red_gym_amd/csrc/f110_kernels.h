@@ -46,18 +46,18 @@ constexpr int REFILL_MIN_IDLE = F110_REFILL_MIN_IDLE; // refill the wave's beam 
 // dt[-1,-1]: the reference's out-of-bounds read (laser_models.py:80-81,:103) becomes an
 // ordinary lookup of a clamped index -- no bounds compare, no select, no index clamp or
 // scaling in the march loop (the loaded value addresses the ds_read directly).
-// Layout: 8-column strips, cell (r, c) of the padded table at [c >> 3][r][c & 7], so one
-// 128-B cache line holds an 8x8-cell block.  The 64 rays of a wave sample neighbouring
+// Layout: 8-column strips, map cell (r, c), r in -1..H, c in -1..W, at [(c >> 3) + 1][r + 1][c & 7] (arithmetic
+// shift: the left border column is the last column of strip 0), so one 128-B cache line holds an 8x8-cell block.  The 64 rays of a wave sample neighbouring
 // points, so a gather touches fewer lines than with a row-major table (which measured
 // ~40 L1 accesses per 64-lane gather and made the kernel L1-tag-rate bound), and the byte
-// offset is one multiply-add: (c >> 3) * strip_bytes + r * 16 + (c & 7) * 2.
+// offset is one shift-add and one multiply-add: (c >> 3) * strip_bytes + ((r << 4) + strip_bytes + 16 | (c & 7) * 2).
 constexpr int LUT_LDS = 1024;                           // LDS LUT slots
 constexpr unsigned SLOT_FAR = LUT_LDS - 2, SLOT_BORDER = LUT_LDS - 1;
 constexpr unsigned OFF_FAR = 8 * SLOT_FAR, OFF_BORDER = 8 * SLOT_BORDER;
 constexpr unsigned CODE_ESC = 65535;                    // second table: read the fp64 table instead
 
 struct MapDev {
-    const uint16_t *cells;  // padded strips [ceil((W+2)/8)][Hp][8] of LDS byte offsets
+    const uint16_t *cells;  // padded strips [(W >> 3) + 2][Hp][8] of LDS byte offsets
     const uint16_t *cells_far; // same layout: rank (<= 65534) of the cells marked OFF_FAR, 65535 = fp64 table
     unsigned cells_bytes;
     unsigned strip_bytes;   // Hp * 16, Hp = H + 2 rounded up to a multiple of 8
@@ -71,7 +71,7 @@ struct MapDev {
 // device-side view of MapDev with the cell table behind a buffer resource descriptor
 struct MapView {
     __amdgpu_buffer_rsrc_t cells_rsrc;
-    unsigned strip_bytes;
+    unsigned strip_bytes, row_bias; // row_bias = strip_bytes + 16
     const double *lut, *dt;
     const uint16_t *cells_far;
     int H, W;
@@ -79,7 +79,7 @@ struct MapView {
     double nox, noy; // -ox * rinv, -oy * rinv (exact when rinv is a power of two)
     __device__ void init(const MapDev &m)
     {
-        strip_bytes = m.strip_bytes; lut = m.lut; dt = m.dt; cells_far = m.cells_far; H = m.H; W = m.W; res = m.res; rinv = m.rinv;
+        strip_bytes = m.strip_bytes; row_bias = m.strip_bytes + 16u; lut = m.lut; dt = m.dt; cells_far = m.cells_far; H = m.H; W = m.W; res = m.res; rinv = m.rinv;
         ox = m.ox; oy = m.oy; oc = m.oc; os = m.os; wres = m.wres; hres = m.hres;
         nox = -m.ox * m.rinv; noy = -m.oy * m.rinv;
     }
@@ -131,13 +131,15 @@ __device__ inline double dist_lookup(const MapView &m, const double *lds_lut, do
             }
         }
     }
-    const int cc = med3_i32(ci, -1, m.W) + 1;  // padded column 0..W+1
-    const int rr = med3_i32(ri, -1, m.H);      // padded row - 1 (the +1 is the +16 below)
-    // byte offset of padded cell (rr + 1, cc): rows are 16 bytes inside a strip (the +16 of the
-    // border row rides in the shift-add, so the offset never goes negative)
-    unsigned row16; // (rr + 1) * 16 in one op; asm so that the +16 is not re-associated into a trailing add
-    asm("v_lshl_add_u32 %0, %1, 4, 16" : "=v"(row16) : "v"(rr));
-    unsigned off = __umul24((unsigned)cc >> 3, m.strip_bytes) + (row16 | (((unsigned)cc << 1) & 14u));
+    const int cc = med3_i32(ci, -1, m.W);      // column -1..W (both ends are border cells)
+    const int rr = med3_i32(ri, -1, m.H);      // row -1..H
+    // Byte offset of cell (rr, cc): strip (cc >> 3) + 1 (arithmetic shift: column -1 is the last column of
+    // strip 0), 16 bytes per row inside a strip.  The +1 strip and the +1 border row ride in the constant
+    // of the shift-add (`row_bias` = strip_bytes + 16, a multiple of 16), so no add is spent on the padding
+    // and the offset never goes negative; asm so that the constant is not re-associated into a trailing add.
+    unsigned row16;
+    asm("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(row16) : "v"(rr), "s"(m.row_bias));
+    unsigned off = (unsigned)(__mul24(cc >> 3, (int)m.strip_bytes) + (int)(row16 | (((unsigned)cc << 1) & 14u)));
     // a finished ray presents an out-of-range offset: the hardware range check answers 0
     // (= LDS offset 0 = distance 0.0, which parks the ray: total += 0, x += 0*c) without
     // occupying the L1 tag pipeline
@@ -153,7 +155,7 @@ __device__ inline double dist_lookup(const MapView &m, const double *lds_lut, do
     if (__builtin_expect(vote(far) != 0ull, 0)) {
         if (far) {
             const unsigned rank = *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(m.cells_far) + (size_t)off);
-            d = (rank != CODE_ESC) ? m.lut[rank] : m.dt[(size_t)(unsigned)rr * (unsigned)m.W + (unsigned)(cc - 1)];
+            d = (rank != CODE_ESC) ? m.lut[rank] : m.dt[(size_t)(unsigned)rr * (unsigned)m.W + (unsigned)cc];
         }
     }
     return d;

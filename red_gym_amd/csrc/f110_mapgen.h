@@ -156,8 +156,8 @@ __global__ __launch_bounds__(256) void map_encode_kernel(const unsigned *d2, int
     if (i >= (size_t)H * W) return;
     const unsigned v = d2[i];
     const unsigned rank = d2_rank(bits, word_prefix, v);
-    const size_t r = i / W + 1, c = i % W + 1;
-    const size_t t = ((c >> 3) * (size_t)Hp + r) * 8 + (c & 7);
+    const size_t r = i / W + 1, c = i % W;
+    const size_t t = (((c >> 3) + 1) * (size_t)Hp + r) * 8 + (c & 7);
     cells[t] = (uint16_t)(rank < SLOT_FAR ? 8u * rank : OFF_FAR);
     cells_far[t] = (uint16_t)(rank < CODE_ESC ? rank : CODE_ESC);
     dt[i] = res * sqrt((double)v);
