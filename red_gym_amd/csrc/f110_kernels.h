@@ -50,7 +50,7 @@ constexpr int REFILL_MIN_IDLE = F110_REFILL_MIN_IDLE; // refill the wave's beam 
 // shift: the left border column is the last column of strip 0), so one 128-B cache line holds an 8x8-cell block.  The 64 rays of a wave sample neighbouring
 // points, so a gather touches fewer lines than with a row-major table (which measured
 // ~40 L1 accesses per 64-lane gather and made the kernel L1-tag-rate bound), and the byte
-// offset is one shift-add and one multiply-add: (c >> 3) * strip_bytes + ((r << 4) + strip_bytes + 16 | (c & 7) * 2).
+// offset is two shift-adds and one multiply-add: (c >> 3) * (strip_bytes - 16) + (c << 1) + (r << 4) + strip_bytes + 16.
 constexpr int LUT_LDS = 1024;                           // LDS LUT slots
 constexpr unsigned SLOT_FAR = LUT_LDS - 2, SLOT_BORDER = LUT_LDS - 1;
 constexpr unsigned OFF_FAR = 8 * SLOT_FAR, OFF_BORDER = 8 * SLOT_BORDER;
@@ -71,7 +71,7 @@ struct MapDev {
 // device-side view of MapDev with the cell table behind a buffer resource descriptor
 struct MapView {
     __amdgpu_buffer_rsrc_t cells_rsrc;
-    unsigned strip_bytes, row_bias; // row_bias = strip_bytes + 16
+    unsigned strip_bytes, row_bias, strip_m16; // row_bias = strip_bytes + 16, strip_m16 = strip_bytes - 16
     const double *lut, *dt;
     const uint16_t *cells_far;
     int H, W;
@@ -79,7 +79,7 @@ struct MapView {
     double nox, noy; // -ox * rinv, -oy * rinv (exact when rinv is a power of two)
     __device__ void init(const MapDev &m)
     {
-        strip_bytes = m.strip_bytes; row_bias = m.strip_bytes + 16u; lut = m.lut; dt = m.dt; cells_far = m.cells_far; H = m.H; W = m.W; res = m.res; rinv = m.rinv;
+        strip_bytes = m.strip_bytes; row_bias = m.strip_bytes + 16u; strip_m16 = m.strip_bytes - 16u; lut = m.lut; dt = m.dt; cells_far = m.cells_far; H = m.H; W = m.W; res = m.res; rinv = m.rinv;
         ox = m.ox; oy = m.oy; oc = m.oc; os = m.os; wres = m.wres; hres = m.hres;
         nox = -m.ox * m.rinv; noy = -m.oy * m.rinv;
     }
@@ -137,9 +137,12 @@ __device__ inline double dist_lookup(const MapView &m, const double *lds_lut, do
     // strip 0), 16 bytes per row inside a strip.  The +1 strip and the +1 border row ride in the constant
     // of the shift-add (`row_bias` = strip_bytes + 16, a multiple of 16), so no add is spent on the padding
     // and the offset never goes negative; asm so that the constant is not re-associated into a trailing add.
+    // (c >> 3) * S + (c & 7) * 2 == (c >> 3) * (S - 16) + c * 2: no masking of the column bits needed
     unsigned row16;
     asm("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(row16) : "v"(rr), "s"(m.row_bias));
-    unsigned off = (unsigned)(__mul24(cc >> 3, (int)m.strip_bytes) + (int)(row16 | (((unsigned)cc << 1) & 14u)));
+    unsigned rc;
+    asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(rc) : "v"(cc), "v"(row16));
+    unsigned off = (unsigned)(__mul24(cc >> 3, (int)m.strip_m16) + (int)rc);
     // a finished ray presents an out-of-range offset: the hardware range check answers 0
     // (= LDS offset 0 = distance 0.0, which parks the ray: total += 0, x += 0*c) without
     // occupying the L1 tag pipeline
