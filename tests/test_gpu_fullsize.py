@@ -31,7 +31,10 @@ def test_fullsize_sample_vs_oracle_and_lookup_count(B, A):
     poses = workload.spawn_poses(B, A)
     acts = workload.action_pool(T, B, A)
     rng = np.random.default_rng(9)
-    sample = np.sort(rng.choice(B, size=48, replace=False))
+    # random envs plus the ends of the launch: the last 2 048 cars run as four short waves each (launch_scan),
+    # so the sample straddles that boundary on purpose
+    tail0 = B - 2048 // A
+    sample = np.unique(np.r_[rng.choice(B, size=40, replace=False), 0, 1, tail0 - 2, tail0 - 1, tail0, tail0 + 1, B - 2, B - 1])
     sc = oracle.Scanner(1080, 2 * np.pi)
     sc.set_map(workload.EXAMPLE_MAP + '.yaml', '.png')
     noise = oracle.noise_table(12345, T + 2)
