@@ -194,7 +194,7 @@ class Engine(object):
         import torch
         oc, os_ = float(np.cos(orig_theta)), float(np.sin(orig_theta))
         if torch.is_tensor(free) and free.is_cuda:
-            f = free.to(torch.uint8).contiguous()
+            f = free.to(device=self.device, dtype=torch.uint8).contiguous()
             if not bool((f == 0).any()):
                 raise ValueError('map has no occupied cell')
             H, W = f.shape
