@@ -284,6 +284,7 @@ def test_hipgraph_replay_equals_eager(assets):
     dict(map='maps/berlin', fov=4.7, num_beams=1080, A=2, ego_idx=1, integ='RK4'),      # res 0.05: guarded-reciprocal index path
     dict(map='maps/skirk', fov=2 * np.pi, num_beams=271, A=1, ego_idx=0, integ='Euler'),  # odd beam count (partial chunk)
     dict(map='example_map', fov=3.0, num_beams=64, A=3, ego_idx=2, integ='RK4'),          # one chunk, three agents
+    dict(map='maps/vegas', fov=2 * np.pi, num_beams=4096, A=8, ego_idx=7, integ='RK4'),   # both maxima: beams and agents
 ])
 def test_step_path_odd_configs_vs_oracle(assets, cfg):
     """Whole step path (dynamics, scan+noise+iTTC, opponents, GJK, lap logic) on other maps /
