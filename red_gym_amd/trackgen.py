@@ -1,17 +1,17 @@
 """Random closed tracks for domain randomisation.
 
-`create_centerline` restates the track walker of the reference's generator
-(gym/f110_gym/unittest/random_trackgen.py:56-159, itself adapted from CarRacing-v0): 16 random checkpoints on a
-ring, a point that steers towards the next checkpoint in steps of 3.5 units, the last closed lap cut out.  It
-draws from NumPy's legacy global-style `RandomState` in the reference's call order, so a seed gives the same
-centre line as `np.random.seed(seed)` does there.
+`create_centerline` produces the centre line of the reference's generator
+(gym/f110_gym/unittest/random_trackgen.py:56-159, itself adapted from CarRacing-v0): 16 random gates on a ring, a
+point that steers towards the next gate in strides of 3.5 units, the last closed lap cut out.  It consumes NumPy's
+legacy `RandomState` stream in the reference's draw order and performs the same floating-point operations, so a
+seed gives the centre line that `np.random.seed(seed)` gives there.
 
 The reference then offsets the centre line by +-10 units with shapely, strokes both curves with matplotlib
 (linewidth 3, 20x20 in at 80 dpi) and re-reads the PNG with cv2 (:161-218).  None of that is reproducible here
 (cv2 / shapely absent, matplotlib's anti-aliased rendering is not a specification), so the walls are drawn by
 their definition instead: a pixel is a wall iff its distance to the centre line is within half a stroke of the
 offset -- `track_mask_kernel` on the GPU, followed by the device map pipeline.  PARITY UNPINNED for the image;
-the centre line follows the reference's arithmetic statement by statement.
+the centre line follows the reference's arithmetic operation by operation.
 """
 import math
 
@@ -33,101 +33,95 @@ METRES_PER_UNIT = RESOLUTION / UNITS_PER_PIXEL
 STROKE_PIXELS = 3 * 80 / 72.0     # linewidth 3 pt at 80 dpi
 
 
-def create_centerline(rng):
-    """random_trackgen.py:56-159.  rng: np.random.RandomState (or the np.random module).  Returns the closed centre
-    line [N, 2] in track units, or None where the reference returns False (caller retries)."""
-    start_alpha = 0.
-    checkpoints = []
+def _checkpoints(rng):
+    """Sixteen gates on a ring (:63-77): gate c sits at angle 2*pi*c/16 plus a random part of one sector, at a random
+    radius between a third of and the full track radius; the first and the last gate are pinned far out on the
+    positive x side so that the lap closes there.  The 32 uniforms are drawn as one [16, 2] block -- RandomState
+    fills it row by row, i.e. (angle, radius) per gate, the reference's draw order, and `lo + (hi - lo) * u` is how
+    RandomState.uniform maps them."""
+    sector = 2 * math.pi / CHECKPOINTS
+    u = rng.random_sample((CHECKPOINTS, 2))
+    gates = []
     for c in range(CHECKPOINTS):
-        alpha = 2 * math.pi * c / CHECKPOINTS + rng.uniform(0, 2 * math.pi * 1 / CHECKPOINTS)
-        rad = rng.uniform(TRACK_RAD / 3, TRACK_RAD)
+        angle = 2 * math.pi * c / CHECKPOINTS + (0.0 + (sector - 0.0) * u[c, 0])
+        radius = TRACK_RAD / 3 + (TRACK_RAD - TRACK_RAD / 3) * u[c, 1]
         if c == 0:
-            alpha = 0
-            rad = 1.5 * TRACK_RAD
-        if c == CHECKPOINTS - 1:
-            alpha = 2 * math.pi * c / CHECKPOINTS
-            start_alpha = 2 * math.pi * (-0.5) / CHECKPOINTS
-            rad = 1.5 * TRACK_RAD
-        checkpoints.append((alpha, rad * math.cos(alpha), rad * math.sin(alpha)))
+            angle, radius = 0, 1.5 * TRACK_RAD
+        elif c == CHECKPOINTS - 1:
+            angle, radius = 2 * math.pi * c / CHECKPOINTS, 1.5 * TRACK_RAD
+        gates.append((angle, radius * math.cos(angle), radius * math.sin(angle)))
+    return gates, 2 * math.pi * (-0.5) / CHECKPOINTS
 
-    x, y, beta = 1.5 * TRACK_RAD, 0, 0
-    dest_i = 0
-    laps = 0
-    track = []
-    no_freeze = 2500
-    visited_other_side = False
-    while True:
-        alpha = math.atan2(y, x)
-        if visited_other_side and alpha > 0:
-            laps += 1
-            visited_other_side = False
-        if alpha < 0:
-            visited_other_side = True
-            alpha += 2 * math.pi
-        while True:
-            failed = True
+
+def _walk(gates):
+    """The walker of :79-129: a point starts at the first gate heading along +y and moves in strides of
+    TRACK_DETAIL_STEP; every stride it turns towards the next gate ahead of its polar angle, by at most
+    TRACK_TURN_RATE.  Returns per stride (polar angle used for gate selection, mean heading, x, y), for at most
+    2500 strides or five completed laps."""
+    n = len(gates)
+    x, y, heading = 1.5 * TRACK_RAD, 0, 0
+    gate, laps, been_below = 0, 0, False
+    trail = []
+    for _ in range(2500):
+        polar = math.atan2(y, x)
+        if been_below and polar > 0:
+            laps, been_below = laps + 1, False
+        if polar < 0:
+            been_below = True
+            polar += 2 * math.pi
+        # first gate at or beyond the polar angle; when the scan runs off the end of the ring it restarts one turn lower
+        target = None
+        while target is None:
             while True:
-                dest_alpha, dest_x, dest_y = checkpoints[dest_i % len(checkpoints)]
-                if alpha <= dest_alpha:
-                    failed = False
+                g = gates[gate % n]
+                if polar <= g[0]:
+                    target = g
                     break
-                dest_i += 1
-                if dest_i % len(checkpoints) == 0:
+                gate += 1
+                if gate % n == 0:
                     break
-            if not failed:
-                break
-            alpha -= 2 * math.pi
-            continue
-        r1x = math.cos(beta)
-        r1y = math.sin(beta)
-        p1x = -r1y
-        p1y = r1x
-        dest_dx = dest_x - x
-        dest_dy = dest_y - y
-        proj = r1x * dest_dx + r1y * dest_dy
-        while beta - alpha > 1.5 * math.pi:
-            beta -= 2 * math.pi
-        while beta - alpha < -1.5 * math.pi:
-            beta += 2 * math.pi
-        prev_beta = beta
-        proj *= SCALE
-        if proj > 0.3:
-            beta -= min(TRACK_TURN_RATE, abs(0.001 * proj))
-        if proj < -0.3:
-            beta += min(TRACK_TURN_RATE, abs(0.001 * proj))
-        x += p1x * TRACK_DETAIL_STEP
-        y += p1y * TRACK_DETAIL_STEP
-        track.append((alpha, prev_beta * 0.5 + beta * 0.5, x, y))
+            if target is None:
+                polar -= 2 * math.pi
+        ux, uy = math.cos(heading), math.sin(heading)      # unit vector at `heading`; the point moves along its normal
+        along = ux * (target[1] - x) + uy * (target[2] - y)
+        while heading - polar > 1.5 * math.pi:
+            heading -= 2 * math.pi
+        while heading - polar < -1.5 * math.pi:
+            heading += 2 * math.pi
+        before = heading
+        along *= SCALE
+        if along > 0.3:
+            heading -= min(TRACK_TURN_RATE, abs(0.001 * along))
+        if along < -0.3:
+            heading += min(TRACK_TURN_RATE, abs(0.001 * along))
+        x += -uy * TRACK_DETAIL_STEP
+        y += ux * TRACK_DETAIL_STEP
+        trail.append((polar, before * 0.5 + heading * 0.5, x, y))
         if laps > 4:
             break
-        no_freeze -= 1
-        if no_freeze == 0:
-            break
+    return trail
 
-    # the last closed lap (:131-146)
-    i1, i2 = -1, -1
-    i = len(track)
-    while True:
-        i -= 1
-        if i == 0:
-            return None
-        pass_through_start = track[i][0] > start_alpha and track[i - 1][0] <= start_alpha
-        if pass_through_start and i2 == -1:
-            i2 = i
-        elif pass_through_start and i1 == -1:
-            i1 = i
-            break
-    track = track[i1:i2 - 1]
-    if len(track) < 3:
+
+def create_centerline(rng):
+    """random_trackgen.py:56-159.  rng: np.random.RandomState.  Returns the closed centre line [N, 2] in track units,
+    or None where the reference gives up (caller retries)."""
+    gates, start_angle = _checkpoints(rng)
+    trail = np.asarray(_walk(gates), dtype=np.float64)
+    # the last closed lap (:131-146): the two latest strides whose polar angle steps over the start angle
+    polar = trail[:, 0]
+    crossings = np.flatnonzero((polar[1:] > start_angle) & (polar[:-1] <= start_angle)) + 1
+    if len(crossings) < 2:
         return None
-    first_beta = track[0][1]
-    first_perp_x = math.cos(first_beta)
-    first_perp_y = math.sin(first_beta)
-    well_glued_together = np.sqrt(np.square(first_perp_x * (track[0][2] - track[-1][2])) +
-                                  np.square(first_perp_y * (track[0][3] - track[-1][3])))
-    if well_glued_together > TRACK_DETAIL_STEP:
+    first, last = int(crossings[-2]), int(crossings[-1])
+    lap = trail[first:last - 1]
+    if len(lap) < 3:
         return None
-    return np.asarray([(px, py) for (_, _, px, py) in track], dtype=np.float64)
+    # head and tail must meet within one stride, measured across the first stride's heading (:149-158)
+    px, py = math.cos(lap[0, 1]), math.sin(lap[0, 1])
+    gap = np.sqrt(np.square(px * (lap[0, 2] - lap[-1, 2])) + np.square(py * (lap[0, 3] - lap[-1, 3])))
+    if gap > TRACK_DETAIL_STEP:
+        return None
+    return np.ascontiguousarray(lap[:, 2:4])
 
 
 def random_centerline(seed, max_tries=64):

@@ -24,16 +24,22 @@ def test_centerline_is_closed_deterministic_and_evenly_stepped():
 
 
 def test_rng_draw_order_matches_the_reference_statement():
-    """Two uniforms per checkpoint, angle first (:67-68): the walker consumes exactly 32 draws per attempt."""
-    class Counting(np.random.RandomState):
-        n = 0
-
-        def uniform(self, *a, **k):
-            Counting.n += 1
-            return super().uniform(*a, **k)
-    rng = Counting(123)
-    tg.create_centerline(rng)
-    assert Counting.n == 2 * tg.CHECKPOINTS
+    """The reference draws two uniforms per gate, angle first (:67-68), with RandomState.uniform; the generator
+    takes them as one [16, 2] block of random_sample.  Same stream, same values, same generator state after."""
+    import math
+    for seed in (0, 123, 4242):
+        a, b = np.random.RandomState(seed), np.random.RandomState(seed)
+        gates, start_angle = tg._checkpoints(a)
+        for c in range(tg.CHECKPOINTS):
+            ang = 2 * math.pi * c / tg.CHECKPOINTS + b.uniform(0, 2 * math.pi * 1 / tg.CHECKPOINTS)
+            rad = b.uniform(tg.TRACK_RAD / 3, tg.TRACK_RAD)
+            if c == 0:
+                ang, rad = 0, 1.5 * tg.TRACK_RAD
+            if c == tg.CHECKPOINTS - 1:
+                ang, rad = 2 * math.pi * c / tg.CHECKPOINTS, 1.5 * tg.TRACK_RAD
+            assert gates[c] == (ang, rad * math.cos(ang), rad * math.sin(ang))
+        assert start_angle == 2 * math.pi * (-0.5) / tg.CHECKPOINTS
+        assert a.random_sample() == b.random_sample()
 
 
 def test_raster_frame_holds_every_track():
