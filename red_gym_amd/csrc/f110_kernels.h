@@ -72,14 +72,14 @@ struct MapDev {
 struct MapView {
     __amdgpu_buffer_rsrc_t cells_rsrc;
     unsigned strip_bytes, row_bias, strip_m16; // row_bias = strip_bytes + 16, strip_m16 = strip_bytes - 16
-    const double *lut, *dt;
-    const uint16_t *cells_far;
+    const MapDev *desc;  // rare paths (far cells, escape cells) re-read their table pointers from the descriptor:
+                         // three 64-bit pointers less to keep in scalar registers across the march loop
     int H, W;
     double res, rinv, ox, oy, oc, os, wres, hres;
     double nox, noy; // -ox * rinv, -oy * rinv (exact when rinv is a power of two)
     __device__ void init(const MapDev &m)
     {
-        strip_bytes = m.strip_bytes; row_bias = m.strip_bytes + 16u; strip_m16 = m.strip_bytes - 16u; lut = m.lut; dt = m.dt; cells_far = m.cells_far; H = m.H; W = m.W; res = m.res; rinv = m.rinv;
+        strip_bytes = m.strip_bytes; row_bias = m.strip_bytes + 16u; strip_m16 = m.strip_bytes - 16u; desc = &m; H = m.H; W = m.W; res = m.res; rinv = m.rinv;
         ox = m.ox; oy = m.oy; oc = m.oc; os = m.os; wres = m.wres; hres = m.hres;
         nox = -m.ox * m.rinv; noy = -m.oy * m.rinv;
     }
@@ -157,8 +157,10 @@ __device__ inline double dist_lookup(const MapView &m, const double *lds_lut, do
     const bool far = code == OFF_FAR;
     if (__builtin_expect(vote(far) != 0ull, 0)) {
         if (far) {
-            const unsigned rank = *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(m.cells_far) + (size_t)off);
-            d = (rank != CODE_ESC) ? m.lut[rank] : m.dt[(size_t)(unsigned)rr * (unsigned)m.W + (unsigned)cc];
+            const MapDev *dp = m.desc;
+            asm volatile("" : "+s"(dp)); // opaque: the loads below stay here instead of being hoisted to the kernel entry
+            const unsigned rank = *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(dp->cells_far) + (size_t)off);
+            d = (rank != CODE_ESC) ? dp->lut[rank] : dp->dt[(size_t)(unsigned)rr * (unsigned)m.W + (unsigned)cc];
         }
     }
     return d;
@@ -252,6 +254,13 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
 {
     __shared__ __attribute__((aligned(16))) double s_lut[LUT_LDS];
     __shared__ int s_chunk0[MAX_CHUNKS];
+    // the same argument block addressed through the kernarg segment (ScanArgs is the only kernel argument): rarely
+    // needed fields are re-read through it where they are used instead of being held in SGPRs for the whole kernel
+#if defined(__HIP_DEVICE_COMPILE__)
+    const ScanArgs *rare = (const ScanArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+#else
+    const ScanArgs *rare = &a; // host pass of the single-source compile: never executed
+#endif
     const int nb = a.scan.nb;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int wid = blockIdx.x * SCAN_WAVES + wave; // wave-uniform (scalar)
@@ -313,9 +322,11 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
         if (do_ttc) {
             const double sd = v - sdv;
             if (__builtin_expect(fabs(sd) < cand, 0)) {
-                const double proj_vel = vel * a.beam_cosines[i];
+                const ScanArgs *ra = rare;
+                asm volatile("" : "+s"(ra)); // re-read the rarely needed arguments here instead of holding them in SGPRs
+                const double proj_vel = vel * ra->beam_cosines[i];
                 const double ttc = sd / proj_vel;
-                if ((ttc < a.ttc_thresh) && (ttc >= 0.0)) hit = true;
+                if ((ttc < ra->ttc_thresh) && (ttc >= 0.0)) hit = true;
             }
         }
     };
@@ -400,12 +411,14 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
             } while (nact > go);
         }
     }
-    if (a.lookups && lane == 0) atomicAdd(&a.lookups[car], nlook);
+    const ScanArgs *ra = rare;
+    asm volatile("" : "+s"(ra));
+    if (ra->lookups && lane == 0) atomicAdd(&ra->lookups[car], nlook);
 
     // ---- iTTC result: the flag only; env_kernel zeroes the state (base_classes.py:241-250)
     // once every wave of the car is done.  Plain store: all writers store the same 1.
     if (STEP) {
-        if (vote(hit) != 0ull && lane == 0) a.in_collision[car] = 1;
+        if (vote(hit) != 0ull && lane == 0) ra->in_collision[car] = 1;
     }
 }
 
