@@ -735,7 +735,8 @@ static ScanDev scan_dev(const f110_handle *h)
 template <bool STEP>
 static int launch_scan_t(f110_handle *h, const ScanArgs &a, hipStream_t st)
 {
-    const int waves = a.wpc == 1 ? (a.n_cars - a.n_tail) + a.n_tail * TAIL_WPC : a.n_cars * a.wpc;
+    int waves = 0;
+    for (int i = 0; i < a.n_stages; i++) waves += a.stage_cars[i] << a.stage_log2w[i];
     const dim3 grid((waves + SCAN_WAVES - 1) / SCAN_WAVES), block(SCAN_THREADS);
     if (h->ident && h->pow2) hipLaunchKernelGGL((scan_kernel<true, true, STEP>), grid, block, 0, st, a);
     else if (h->ident) hipLaunchKernelGGL((scan_kernel<true, false, STEP>), grid, block, 0, st, a);
@@ -767,16 +768,49 @@ static int launch_scan(f110_handle *h, const ScanArgs &a_in, hipStream_t st)
     // Drain of a launch: workgroups are dispatched in index order and nothing follows the last ones,
     // so the chip empties over one wave lifetime (about half of it lost: ~5 % at 65 536 cars -- the gap
     // that two half-size launches from two processes close by overlapping).  The last cars therefore
-    // run as TAIL_WPC short waves each.  Measured (gpurun_out sweeps, profiles/r01j): 65 536 cars
-    // 0.702 -> 0.672 ms for any tail of 1 000 .. 2 048 cars (it has to cover the last of the slowest
-    // cars), 32 768: 0.380 -> 0.368, 16 384: 0.225 -> 0.218, 8 192: neutral, 4 096: 0.126 -> 0.105 with
-    // half of the cars split.  F110_TAIL_CARS overrides the count.
-    static const char *tail_env = getenv("F110_TAIL_CARS");
-    int n_tail = 0;
-    if (a.wpc == 1 && (a.scan.nb + 63) / 64 >= TAIL_WPC) n_tail = tail_env ? atoi(tail_env) : std::min(2048, a.n_cars / 2);
-    n_tail = std::max(0, std::min(n_tail, a.n_cars));
-    if (n_tail > 0 && ((a.n_cars - n_tail) % SCAN_WAVES)) n_tail = std::min(a.n_cars, n_tail + (a.n_cars - n_tail) % SCAN_WAVES); // a workgroup never mixes a whole car with a split one
-    a.n_tail = n_tail;
+    // run as 4 short waves each: the wave -> car mapping is a list of stages (cars, log2 waves per car).
+    // Measured (profiles/r01j): 65 536 cars 0.702 -> 0.672 ms for any tail of 1 000 .. 2 048 cars (it has to
+    // cover the last of the slowest cars), 32 768: 0.380 -> 0.368, 16 384: 0.225 -> 0.218, 8 192: neutral,
+    // 4 096: 0.126 -> 0.105 with half of the cars split; graded tails (halves, quarters, eighths) and graded
+    // heads changed nothing.  F110_STAGES="cars:log2waves,..." with one "*" for the remaining cars overrides
+    // the choice below (e.g. "*:0,2048:2" is the default for big launches).
+    static const char *stages_env = getenv("F110_STAGES");
+    const int nch = (a.scan.nb + 63) / 64;
+    int lg_all = a.wpc >= 8 ? 3 : a.wpc >= 4 ? 2 : a.wpc >= 2 ? 1 : 0;
+    struct St { int cars, lg; };
+    std::vector<St> stv;
+    if (lg_all > 0 || nch < 8) stv.push_back({a.n_cars, lg_all});
+    else {
+        std::vector<St> spec;
+        if (stages_env) {
+            const char *p = stages_env;
+            while (*p) {
+                int cars = -1, lg = 0;
+                if (*p == '*') { p++; } else cars = (int)strtol(p, (char **)&p, 10);
+                if (*p == ':') lg = (int)strtol(p + 1, (char **)&p, 10);
+                spec.push_back({cars, std::max(0, std::min(3, lg))});
+                if (*p == ',') p++; else break;
+            }
+        } else {
+            const int tail = std::min(2048, a.n_cars / 2);
+            spec = {{-1, 0}, {tail, 2}};
+        }
+        int fixed = 0;
+        for (auto &x : spec) if (x.cars >= 0) { x.cars -= x.cars % SCAN_WAVES; fixed += x.cars; }
+        if (fixed > a.n_cars || spec.size() > 8) { spec = {{-1, 0}}; fixed = 0; }
+        bool star = false;
+        for (auto &x : spec) if (x.cars < 0 && !star) { x.cars = a.n_cars - fixed; star = true; }
+        if (!star) spec.push_back({a.n_cars - fixed, 0});
+        for (auto &x : spec) if (x.cars > 0) stv.push_back(x);
+        // a workgroup never mixes two stages: every stage's wave count is a multiple of SCAN_WAVES
+        for (size_t i = 0; i + 1 < stv.size(); i++) {
+            const int w = stv[i].cars << stv[i].lg;
+            if (w % SCAN_WAVES) { stv.assign(1, {a.n_cars, 0}); break; }
+        }
+    }
+    if (stv.size() > 8) stv.assign(1, {a.n_cars, 0});
+    a.n_stages = (int)stv.size();
+    for (int i = 0; i < 8; i++) { a.stage_cars[i] = i < a.n_stages ? stv[i].cars : 0; a.stage_log2w[i] = i < a.n_stages ? stv[i].lg : 0; }
     return a.state ? launch_scan_t<true>(h, a, st) : launch_scan_t<false>(h, a, st);
 }
 

@@ -214,7 +214,11 @@ struct ScanArgs {
     int agents;             // A (cars of one env are consecutive)
     int wpc;                // wavefronts per car (power of two): small batches split a car's beams over
                             // several waves so that the chip is still filled; chunk position p goes to wave p % wpc
-    int n_tail;             // wpc == 1 only: the LAST n_tail cars run as TAIL_WPC short waves each (see launch_scan)
+    // Wave -> (car, part) mapping: consecutive STAGES of cars, stage s giving each of its stage_cars[s] cars
+    // 2^stage_log2w[s] waves (launch_scan explains the choice).  Read through `rare`, not held in registers.
+    int n_stages;
+    int stage_cars[8];
+    int stage_log2w[8];
     // pose source: pose = (src[car*stride], src[car*stride+1], src[car*stride+yaw_off])
     const double *pose_src;
     int pose_stride, yaw_off;
@@ -241,10 +245,6 @@ struct ScanArgs {
 // use is the 8 KiB distance LUT shared by the workgroup, so occupancy is register-bound.
 // STEP: full env step (noise + iTTC + state update); false: ScanSimulator2D.scan(pose, None).
 constexpr int MAX_CHUNKS = 64; // beams are handed out in chunks of 64 (num_beams <= 4096)
-#ifndef F110_TAIL_WPC
-#define F110_TAIL_WPC 4
-#endif
-constexpr int TAIL_WPC = F110_TAIL_WPC; // waves per car for the last cars of a big launch
 
 template <bool IDENT, bool POW2, bool STEP>
 #ifndef F110_SCAN_MIN_WAVES
@@ -266,13 +266,17 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
     const int wid = blockIdx.x * SCAN_WAVES + wave; // wave-uniform (scalar)
     // wave -> (car, part of its beam queue).  Kept to one extra argument and shifts: this kernel sits at
     // the 80-SGPR budget of 8 waves/SIMD, and a scalar spilled inside the refill loop costs ~3 % of the launch.
-    int wpc = a.wpc, car, part;
-    if (wpc == 1) {
-        const int head = a.n_cars - a.n_tail;
-        if (wid < head) { car = wid; part = 0; }
-        else { wpc = TAIL_WPC; car = head + (wid - head) / TAIL_WPC; part = (wid - head) % TAIL_WPC; }
-    } else {
-        car = wid / wpc; part = wid % wpc;
+    int wpc, car, part;
+    {
+        int t = wid, c = 0, st = 0;
+        const int ns = rare->n_stages;
+        for (; st < ns; st++) {
+            const int cars_s = rare->stage_cars[st], w = cars_s << rare->stage_log2w[st];
+            if (t < w) break;
+            t -= w; c += cars_s;
+        }
+        const int lg = st < ns ? rare->stage_log2w[st] : 0;
+        wpc = 1 << lg; car = st < ns ? c + (t >> lg) : a.n_cars; part = t & (wpc - 1);
     }
     // the car's map (wave-uniform: scalar loads); waves past the last car still help to stage the LUT
     const int car_c = min(car, a.n_cars - 1);
