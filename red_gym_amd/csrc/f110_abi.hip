@@ -8,6 +8,8 @@
 #include "f110_bitmap.h"
 #include "f110_mapgen.h"
 
+#include <hip/hip_ext.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -732,16 +734,18 @@ static ScanDev scan_dev(const f110_handle *h)
     return s;
 }
 
+// ev0 / ev1 (measurement aid, may be null): start / stop events attached to the dispatch itself, which costs
+// less than bracketing the launch with two hipEventRecord calls (those add two barrier packets to the queue)
 template <bool STEP>
-static int launch_scan_t(f110_handle *h, const ScanArgs &a, hipStream_t st)
+static int launch_scan_t(f110_handle *h, const ScanArgs &a, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr)
 {
     int waves = 0;
     for (int i = 0; i < a.n_stages; i++) waves += a.stage_cars[i] << a.stage_log2w[i];
     const dim3 grid((waves + SCAN_WAVES - 1) / SCAN_WAVES), block(SCAN_THREADS);
-    if (h->ident && h->pow2) hipLaunchKernelGGL((scan_kernel<true, true, STEP>), grid, block, 0, st, a);
-    else if (h->ident) hipLaunchKernelGGL((scan_kernel<true, false, STEP>), grid, block, 0, st, a);
-    else if (h->pow2) hipLaunchKernelGGL((scan_kernel<false, true, STEP>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((scan_kernel<false, false, STEP>), grid, block, 0, st, a);
+    if (h->ident && h->pow2) hipExtLaunchKernelGGL((scan_kernel<true, true, STEP>), grid, block, 0, st, ev0, ev1, 0, a);
+    else if (h->ident) hipExtLaunchKernelGGL((scan_kernel<true, false, STEP>), grid, block, 0, st, ev0, ev1, 0, a);
+    else if (h->pow2) hipExtLaunchKernelGGL((scan_kernel<false, true, STEP>), grid, block, 0, st, ev0, ev1, 0, a);
+    else hipExtLaunchKernelGGL((scan_kernel<false, false, STEP>), grid, block, 0, st, ev0, ev1, 0, a);
     HIP_TRY(hipGetLastError());
     return F110_OK;
 }
@@ -761,7 +765,7 @@ static int waves_per_car(int n_cars, int num_beams)
     return wpc;
 }
 
-static int launch_scan(f110_handle *h, const ScanArgs &a_in, hipStream_t st)
+static int launch_scan(f110_handle *h, const ScanArgs &a_in, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr)
 {
     ScanArgs a = a_in;
     a.wpc = waves_per_car(a.n_cars, a.scan.nb);
@@ -811,7 +815,7 @@ static int launch_scan(f110_handle *h, const ScanArgs &a_in, hipStream_t st)
     if (stv.size() > 8) stv.assign(1, {a.n_cars, 0});
     a.n_stages = (int)stv.size();
     for (int i = 0; i < 8; i++) { a.stage_cars[i] = i < a.n_stages ? stv[i].cars : 0; a.stage_log2w[i] = i < a.n_stages ? stv[i].lg : 0; }
-    return a.state ? launch_scan_t<true>(h, a, st) : launch_scan_t<false>(h, a, st);
+    return a.state ? launch_scan_t<true>(h, a, st, ev0, ev1) : launch_scan_t<false>(h, a, st, ev0, ev1);
 }
 
 static int run_step(f110_handle *h, const double *actions, int reset_only, hipStream_t st)
@@ -838,10 +842,9 @@ static int run_step(f110_handle *h, const double *actions, int reset_only, hipSt
     s.in_collision = b.in_collision; s.pending_reset = b.pending_reset; s.reset_only = reset_only;
     s.out_f32 = b.scans; s.out_f64 = b.scans_f64; s.lookups = b.lookups;
     const bool prof = h->prof_on && (size_t)(2 * h->prof_n + 1) < h->prof_ev.size();
-    if (prof) HIP_TRY(hipEventRecord(h->prof_ev[2 * h->prof_n], st));
-    int rc = launch_scan(h, s, st);
+    int rc = prof ? launch_scan(h, s, st, h->prof_ev[2 * h->prof_n], h->prof_ev[2 * h->prof_n + 1]) : launch_scan(h, s, st);
     if (rc) return rc;
-    if (prof) { HIP_TRY(hipEventRecord(h->prof_ev[2 * h->prof_n + 1], st)); h->prof_n++; }
+    if (prof) h->prof_n++;
     if (c.num_agents > 1) {
         OppArgs o;
         o.n_cars = N; o.agents = c.num_agents; o.nb = c.num_beams; o.state = b.state; o.pose_snap = b.pose_snap;
