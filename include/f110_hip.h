@@ -175,8 +175,8 @@ int f110_reset(f110_handle *h, const double *poses_dev, const uint8_t *mask_dev,
  * ignore their action and perform reset(spawn) + zero-action step instead. */
 int f110_step(f110_handle *h, const double *actions_dev, void *stream);
 
-/* Measurement aid (bench.py): between begin and end every f110_step brackets its
- * scan_kernel launch with a hipEvent pair on the step's stream (up to max_launches
+/* Measurement aid (bench.py): between begin and end every f110_step attaches a start / stop
+ * hipEvent pair to its scan_kernel dispatch on the step's stream (up to max_launches
  * steps).  f110_profile_end synchronises on the last event and returns the summed
  * kernel time in milliseconds and the number of launches measured. */
 int f110_profile_begin(f110_handle *h, int32_t max_launches);
