@@ -296,3 +296,29 @@ def test_device_mask_map_matches_file_map_scans():
     with pytest.raises(ValueError):
         b.update_map_occupancy(torch.ones((32, 32), dtype=torch.uint8, device='cuda'), 0.05, 0., 0.)
     a.close(); b.close()
+
+
+def test_edt_device_fuzz_small_shapes():
+    """Every shape from 1x1 to 9x13 and a few hundred random masks of random density: device EDT == host EDT."""
+    rng = np.random.default_rng(31)
+    cases = 0
+    for H in range(1, 10):
+        for W in (1, 2, 3, 5, 8, 13):
+            for dens in (0.05, 0.5, 0.95):
+                mask = (rng.random((H, W)) >= dens).astype(np.uint8)
+                mask[rng.integers(H), rng.integers(W)] = 0
+                assert np.array_equal(_edt_dev(mask), _edt_host(mask)), (H, W, dens)
+                cases += 1
+    for _ in range(60):
+        H, W = int(rng.integers(10, 90)), int(rng.integers(10, 140))
+        mask = (rng.random((H, W)) >= rng.choice([0.001, 0.01, 0.2, 0.8])).astype(np.uint8)
+        mask[rng.integers(H), rng.integers(W)] = 0
+        if rng.random() < 0.3:
+            mask[:, rng.integers(W)] = 1            # obstacle-free column
+        if rng.random() < 0.3:
+            mask[rng.integers(H), :] = 1            # obstacle-free row
+        if not (mask == 0).any():
+            mask[0, 0] = 0
+        assert np.array_equal(_edt_dev(mask), _edt_host(mask)), (H, W)
+        cases += 1
+    assert cases > 200
