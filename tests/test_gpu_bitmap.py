@@ -135,3 +135,29 @@ def test_bitmap_full_batch_finishes_and_is_deterministic():
     b = r(scans)
     assert torch.equal(a, b) and torch.equal(a[:64], a[64:128])   # LDS atomics are order-independent
     r.close()
+
+
+def test_bitmap_fuzz_random_options():
+    """Random image sizes, beam counts, scales, start angles and modes, scans with every point in / out of the image."""
+    from oracle import bitmap as ob
+    from red_gym_amd.lidar import LidarBitmap
+    rng = np.random.default_rng(2024)
+    for trial in range(40):
+        nb = int(rng.choice([64, 271, 1080, 2000]))
+        T = int(rng.integers(3, min(nb, 700)))
+        dims = (int(rng.integers(5, 300)), int(rng.integers(5, 300)))
+        if trial % 3 == 0:
+            dims = (int(rng.choice([64, 128, 256])),) * 2        # the vector-store path (cols % 16 == 0)
+        opts = dict(winding_dir=str(rng.choice(['CW', 'CCW'])), starting_angle=float(rng.uniform(-3.2, 3.2)),
+                    scaling_factor=float(rng.choice([0.5, 3.0, 10.0, 40.0])), bg_color=str(rng.choice(['black', 'white'])),
+                    draw_center=bool(rng.integers(2)), output_image_dims=dims, target_beam_count=T,
+                    fov=float(rng.uniform(0.5, 2 * np.pi)), draw_mode=str(rng.choice(['FILL', 'POLYGON', 'RAYS'])),
+                    channels=int(rng.choice([1, 3, 4])))
+        scans = rng.uniform(0, float(rng.choice([0.5, 5.0, 30.0])), (5, nb))
+        scans[0] = 0.0                                           # degenerate: every point on the centre
+        scans[1, ::7] *= 10                                      # spikes far outside the image
+        want = ob.lidar_to_bitmap(scans, **opts)
+        r = LidarBitmap(nb, **opts)
+        got = r(torch.as_tensor(scans, device='cuda')).cpu().numpy()
+        assert np.array_equal(got, want), (trial, opts)
+        r.close()
