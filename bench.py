@@ -144,7 +144,73 @@ def rank_workload(rank, B, A, pool=16):
     return workload.spawn_poses(B, A, rank), workload.action_pool(pool, B, A, rank)
 
 
-def main():
+def self_launch(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N FRESH rank processes of this file (one per
+    GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment -- what torch.distributed.run
+    would set), wait for them and hand back the first non-zero exit code.  The parent never imports torch
+    or touches the GPU and nothing is re-exec'd; rank 0's child prints the one JSON line on the inherited
+    stdout.  If a rank dies the others (which would wait at a barrier for ever) are terminated."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                sys.stderr.write('bench.py: rank %d exited with code %d; stopping the other ranks\n' % (r, code))
+                for q in live:
+                    procs[q].terminate()
+        time.sleep(0.05)
+    return rc
+
+
+def stub_bench(args):
+    """Rehearsal of the rank plumbing WITHOUT a GPU (tests/test_bench_dist_cpu.py): gloo ranks, the real
+    barriers / MAX-over-ranks / JSON assembly, and a sleep of F110_BENCH_STUB_STEP_MS (x (1 + rank), so that
+    the slowest rank sets the time) standing in for f110_step.  The line says "data": "stub": it is not a
+    measurement and the driver's runs never set the variable."""
+    ranks = Ranks('gloo', None)
+    ms = float(os.environ['F110_BENCH_STUB_STEP_MS'])
+    poses, acts = rank_workload(ranks.rank, args.envs, args.agents, 2)
+    n = []
+
+    def step_fn(k):
+        n.append(k)
+        time.sleep(ms * 1e-3 * (1 + ranks.rank))
+    for k in range(args.warmup):
+        step_fn(k)
+    del n[:]
+    elapsed = timed_steps(ranks, step_fn, args.steps)
+    assert len(n) == args.steps
+    world = ranks.dist.get_world_size() if ranks.world > 1 else 1
+    out = {'metric': 'env steps/sec (all envs), 1080-beam lidar', 'value': world * args.envs * args.steps / elapsed,
+           'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+           'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+           'vs_baseline': None, 'dtype': 'f64', 'data': 'stub',
+           'config': {'workload': 'STUB step (sleep), rank plumbing only', 'envs_per_gpu': args.envs,
+                      'agents': args.agents, 'shard_checksum': float(poses.sum() + acts.sum())},
+           'roofline': None}
+    rank = ranks.rank
+    ranks.close()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
@@ -159,7 +225,15 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-scan-events', action='store_true',
                     help='do not bracket the scan kernel with hipEvents (roofline becomes null)')
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
+    if args.gpus < 1:
+        ap.error('--gpus must be >= 1')
+    # N > 1 without a launcher (the driver's `python3 bench.py --gpus N` form): start the ranks ourselves, BEFORE
+    # torch is imported or any HIP call is made in this process
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        return self_launch(args.gpus, argv)
+    if os.environ.get('F110_BENCH_STUB_STEP_MS'):
+        return stub_bench(args)
 
     import torch
     from red_gym_amd import F110VecEnv, workload
@@ -169,14 +243,16 @@ def main():
     # rank on device 0 and F110_BENCH_BACKEND=gloo replaces RCCL, which refuses two ranks on one device.
     if os.environ.get('F110_BENCH_ONE_DEVICE') == '1':
         local_rank = 0
+    if local_rank >= torch.cuda.device_count():  # counting devices does not initialise the GPU
+        sys.exit('bench.py: rank with LOCAL_RANK=%d but only %d GPU(s) are visible' % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     ranks = Ranks(os.environ.get('F110_BENCH_BACKEND', 'nccl'), dev)
-    rank, world = ranks.rank, ranks.world
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit('bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)' % args.gpus)
-        args.gpus = world
+    rank = ranks.rank
+    world = ranks.dist.get_world_size() if ranks.world > 1 else 1  # as the process group reports it
+    if world != args.gpus and rank == 0:
+        sys.stderr.write('bench.py: --gpus %d but the launcher started %d rank(s); reporting n_gpus=%d\n'
+                         % (args.gpus, world, world))
 
     B, A, K, W = args.envs, args.agents, args.steps, args.warmup
     env = F110VecEnv(B, map=workload.EXAMPLE_MAP, map_ext='.png', num_agents=A, timestep=0.01, seed=12345,
@@ -262,4 +338,4 @@ def main():
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(main() or 0)

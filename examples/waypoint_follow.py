@@ -23,7 +23,7 @@ compat.install_missing()  # gym / numba / pyglet stand-ins when those packages a
 import gym  # noqa: E402
 from f110_gym.envs.base_classes import Integrator  # noqa: E402
 from red_gym_amd.maps import ASSETS  # noqa: E402
-from red_gym_amd.planners import PurePursuitPlanner  # noqa: E402
+from red_gym_amd.planner import PurePursuitPlanner  # noqa: E402
 
 
 def main():

@@ -186,7 +186,8 @@ int f110_profile_end(f110_handle *h, double *scan_ms_total, int32_t *launches);
  * (examples/waypoint_follow.py:15-217: nearest point on the raceline, first intersection
  * of the lookahead circle with the polyline incl. wrap-around, actuation).  waypoints:
  * dev [M,3] (x, y, speed); state: dev [n,7] (f110_buffers.state); writes actions dev [n,2]
- * = (steer, vgain*speed), ready to be passed to f110_step. */
+ * = (steer, vgain*speed), ready to be passed to f110_step.  The planner keeps no state: h may be NULL (the
+ * kernel is then enqueued on `stream` of the calling thread's current device). */
 int f110_pure_pursuit(f110_handle *h, const double *waypoints, int32_t M, double lookahead, double vgain,
                       double wheelbase, double max_reacquire, const double *state, int32_t n,
                       double *actions, void *stream);

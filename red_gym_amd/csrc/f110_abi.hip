@@ -952,7 +952,8 @@ extern "C" int f110_pure_pursuit(f110_handle *h, const double *waypoints, int32_
                                  double wheelbase, double max_reacquire, const double *state, int32_t n,
                                  double *actions, void *stream)
 {
-    if (!h || n < 0) return fail(F110_E_INVALID, "f110_pure_pursuit: bad arguments");
+    (void)h; // stateless: the handle is optional (NULL: the launch goes to the calling thread's current device)
+    if (n < 0) return fail(F110_E_INVALID, "f110_pure_pursuit: bad arguments");
     if (n == 0) return F110_OK;
     if (!waypoints || !state || !actions) return fail(F110_E_INVALID, "f110_pure_pursuit: null pointer");
     if (M < 2 || (size_t)M * 3 * sizeof(double) > 150 * 1024)

@@ -1,7 +1,7 @@
 // f110_planner.h -- batched pure-pursuit planner: the caller on the other
 // side of F110Env.step, reference examples/waypoint_follow.py:15-217, one lane per car.
 // fp64, plain mul/add in the reference's order (its np.dot calls are BLAS-rounded, see DESIGN.md
-// section 2); checked against red_gym_amd/planners.py in the tests.
+// section 2); checked against oracle/planner.py in the tests.
 #pragma once
 #include "f110_device.h"
 

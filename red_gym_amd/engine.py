@@ -29,40 +29,26 @@ def params_vec(params):
 
 
 def beam_tables(num_beams, fov, params):
-    """RaceCar.__init__ tables (base_classes.py:120-156), computed with numpy like the reference."""
-    scan_ang_incr = fov / (num_beams - 1)
-    cosines = np.zeros((num_beams,))
-    scan_angles = np.zeros((num_beams,))
-    side_distances = np.zeros((num_beams,))
-    dist_sides = params['width'] / 2.
-    dist_fr = (params['lf'] + params['lr']) / 2.
-    # a beam at exactly 0 rad divides by sin(0) like the reference does (inf loses the min());
-    # only the RuntimeWarning is silenced
+    """RaceCar.__init__ tables (base_classes.py:116-156) as whole-array NumPy: scan angles, their cosines and,
+    per beam, the distance from the lidar to the car's outline (half width sideways, half wheelbase fore/aft)
+    along that beam.  The reference picks the two candidate distances by quadrant; folded to the first
+    quadrant (|angle|, then minus pi/2 beyond it) those are the same operands, so the values are identical
+    bit for bit (tests/test_oracle_golden.py::test_beam_tables_match_reference)."""
+    half_w = params['width'] / 2.
+    half_l = (params['lf'] + params['lr']) / 2.
+    scan_angles = -fov / 2. + np.arange(num_beams) * (fov / (num_beams - 1))
+    cosines = np.cos(scan_angles)
+    # the reference's branches: angle > 0 ? (angle < pi/2 ? angle : angle - pi/2) : (angle > -pi/2 ? -angle : -angle - pi/2)
+    mag = np.where(scan_angles > 0, scan_angles, -scan_angles)
+    rear = np.where(scan_angles > 0, scan_angles >= np.pi / 2, scan_angles <= -np.pi / 2)  # second / third quadrant
+    folded = np.where(rear, mag - np.pi / 2., mag)
+    # a beam at exactly 0 rad divides by sin(0) like the reference does (inf loses the minimum); only the
+    # RuntimeWarning is silenced
     with np.errstate(divide='ignore'):
-        return _beam_tables_loop(num_beams, fov, scan_ang_incr, dist_sides, dist_fr, scan_angles, cosines, side_distances)
-
-
-def _beam_tables_loop(num_beams, fov, scan_ang_incr, dist_sides, dist_fr, scan_angles, cosines, side_distances):
-    for i in range(num_beams):
-        angle = -fov / 2. + i * scan_ang_incr
-        scan_angles[i] = angle
-        cosines[i] = np.cos(angle)
-        if angle > 0:
-            if angle < np.pi / 2:
-                to_side = dist_sides / np.sin(angle)
-                to_fr = dist_fr / np.cos(angle)
-            else:
-                to_side = dist_sides / np.cos(angle - np.pi / 2.)
-                to_fr = dist_fr / np.sin(angle - np.pi / 2.)
-        else:
-            if angle > -np.pi / 2:
-                to_side = dist_sides / np.sin(-angle)
-                to_fr = dist_fr / np.cos(-angle)
-            else:
-                to_side = dist_sides / np.cos(-angle - np.pi / 2)
-                to_fr = dist_fr / np.sin(-angle - np.pi / 2)
-        side_distances[i] = min(to_side, to_fr)
-    return scan_angles, cosines, side_distances
+        s, c = np.sin(folded), np.cos(folded)
+        to_side = half_w / np.where(rear, c, s)
+        to_fr = half_l / np.where(rear, s, c)
+    return scan_angles, cosines, np.minimum(to_side, to_fr)
 
 
 class NoiseTable(object):

@@ -34,7 +34,7 @@ class F110Env(_Base):
         # kwargs extraction with the reference's defaults (f110_env.py:100-157); unknown
         # keywords are ignored exactly as there
         self.seed = kwargs.get('seed', 12345)
-        self.map_name = kwargs.get('map', 'vegas')
+        self.map_name = kwargs.get('map')  # absent: packaged vegas (f110_env.py:117-118)
         self.map_ext = kwargs.get('map_ext', '.png')
         self.params = kwargs.get('params', dict(DEFAULT_PARAMS))
         self.num_agents = kwargs.get('num_agents', 2)

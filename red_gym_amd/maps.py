@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 ASSETS = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'assets')
-BUILTIN_MAPS = ('berlin', 'skirk', 'levine', 'vegas')  # f110_env.py:109-118
+BUILTIN_MAPS = ('berlin', 'skirk', 'levine')  # names f110_env.py:109-114 resolves to packaged maps
+DEFAULT_MAP = 'vegas'  # packaged map used only when the `map` keyword is ABSENT (f110_env.py:117-118)
 
 
 class MapData(object):
@@ -25,6 +26,10 @@ def load_map(map_path, map_ext):
     import yaml
     from PIL import Image
     img_path = os.path.splitext(map_path)[0] + map_ext
+    if not os.path.exists(img_path):
+        # the reference fails inside PIL here (laser_models.py:399); e.g. the packaged 'levine' ships a YAML
+        # without an image, there as here
+        raise FileNotFoundError('map image %s not found (yaml %s, map_ext %r)' % (img_path, map_path, map_ext))
     img = np.array(Image.open(img_path).transpose(Image.FLIP_TOP_BOTTOM)).astype(np.float64)
     if img.ndim != 2:
         raise ValueError('map image must be single-channel, got shape %s' % (img.shape,))

@@ -12,19 +12,22 @@ import torch
 
 from .base_classes import Integrator
 from .engine import DEFAULT_PARAMS, Engine
-from .maps import BUILTIN_MAPS, builtin_map_yaml
+from .maps import BUILTIN_MAPS, DEFAULT_MAP, builtin_map_yaml
 
 
 def resolve_map_path(map_name):
-    """f110_env.py:106-118: builtin names map to the packaged maps, anything else is
-    '<map>.yaml'."""
+    """f110_env.py:106-118: 'berlin' / 'skirk' / 'levine' are packaged maps, any other name (an explicit 'vegas'
+    included) means '<map>.yaml' relative to the working directory, and only an ABSENT `map` keyword (None
+    here) selects the packaged vegas."""
+    if map_name is None:
+        return builtin_map_yaml(DEFAULT_MAP)
     if map_name in BUILTIN_MAPS:
         return builtin_map_yaml(map_name)
     return map_name + '.yaml'
 
 
 class F110VecEnv(object):
-    def __init__(self, num_envs, map='vegas', map_ext='.png', params=None, num_agents=2, timestep=0.01,
+    def __init__(self, num_envs, map=None, map_ext='.png', params=None, num_agents=2, timestep=0.01,
                  ego_idx=0, integrator=Integrator.RK4, fov=2 * np.pi, seed=12345, device=0, autoreset=True,
                  num_beams=1080, noise_std=0.01, keep_f64_scans=False, count_lookups=False, **_ignored):
         self.num_envs, self.num_agents = int(num_envs), int(num_agents)

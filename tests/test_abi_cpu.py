@@ -81,14 +81,19 @@ def test_map_loader_matches_oracle_loader(assets):
 
 
 def test_product_never_imports_oracle():
-    """The shipped package must not reference oracle/ (judge rule: no CPU fallback)."""
-    pkg = os.path.join(ROOT, 'red_gym_amd')
-    for dirpath, _, files in os.walk(pkg):
-        for f in files:
-            if f.endswith(('.py', '.h', '.hip', '.cpp')):
-                src = open(os.path.join(dirpath, f)).read()
-                assert 'import oracle' not in src and 'from oracle' not in src, f
-                assert 'f110_oracle' not in src, f
+    """The shipped package, its drop-in shims and the examples must not reference oracle/ (judge rule: no CPU
+    fallback, the checker is test infrastructure); bench.py may, in its cpu_baseline leg only."""
+    for top in ('red_gym_amd', 'f110_gym', 'weap_util', 'examples', 'include'):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, top)):
+            for f in files:
+                if f.endswith(('.py', '.h', '.hip', '.cpp')):
+                    src = open(os.path.join(dirpath, f)).read()
+                    assert 'import oracle' not in src and 'from oracle' not in src, os.path.join(dirpath, f)
+                    assert 'f110_oracle' not in src and 'oracle/_build' not in src, os.path.join(dirpath, f)
+    bench = open(os.path.join(ROOT, 'bench.py')).read()
+    leg = bench[bench.index('def cpu_baseline('):bench.index('class Ranks(')]
+    rest = bench.replace(leg, '')
+    assert 'import oracle' in leg and 'import oracle' not in rest and 'from oracle' not in rest
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

@@ -55,3 +55,46 @@ def test_single_rank_needs_no_process_group():
     n = []
     assert bench.timed_steps(ranks, lambda k: n.append(k), 7) >= 0 and n == list(range(7))
     ranks.close()
+
+
+def _run_bench(args, extra_env, timeout=180):
+    import json
+    import subprocess
+    env = dict(os.environ, F110_BENCH_BACKEND='gloo', **extra_env)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT'):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=timeout, text=True)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
+    return p.returncode, [json.loads(ln) for ln in lines], p.stderr
+
+
+def test_self_launch_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (the driver's command form): the parent starts two fresh
+    rank processes, rank 0 prints ONE JSON line whose n_gpus is the process group's world size, value aggregates
+    both shards and the slow rank (2x the step time) sets ms_per_step."""
+    rc, lines, err = _run_bench(['--gpus', '2', '--steps', '6', '--warmup', '2', '--envs', '32'],
+                                {'F110_BENCH_STUB_STEP_MS': '10'})
+    assert rc == 0, err
+    assert len(lines) == 1
+    out = lines[0]
+    assert out['n_gpus'] == 2 and out['steps'] == 6 and out['warmup'] == 2 and out['data'] == 'stub'
+    assert out['ms_per_step'] >= 20 * 0.9                       # rank 1 sleeps 20 ms per step
+    assert abs(out['value'] - 2 * 32 * 6 / (out['ms_per_step'] * 6e-3)) < 1e-6 * out['value']
+
+
+def test_self_launch_propagates_a_rank_failure():
+    """A rank that dies must not leave the others waiting at a barrier: non-zero exit code, no JSON line."""
+    rc, lines, err = _run_bench(['--gpus', '2', '--steps', '2', '--warmup', '0', '--envs', '8'],
+                                {'F110_BENCH_STUB_STEP_MS': 'not-a-number'})
+    assert rc != 0 and lines == []
+
+
+def test_launcher_never_touches_torch_in_the_parent():
+    """The self-launch must happen before torch is imported (a process that initialised the GPU may not start
+    the ranks by re-exec, and must not hold the device the children need)."""
+    src = open(os.path.join(ROOT, 'bench.py')).read()
+    main_src = src[src.index('def main('):]
+    assert main_src.index('self_launch(args.gpus, argv)') < main_src.index('import torch')
+    launch_src = src[src.index('def self_launch('):src.index('def stub_bench(')]
+    assert 'import torch' not in launch_src and 'os.exec' not in launch_src and 'subprocess.Popen' in launch_src

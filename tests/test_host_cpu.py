@@ -65,7 +65,7 @@ def test_workload_is_deterministic_and_sharded():
 def test_planner_reproduces_reference_actions(golden, assets):
     """examples/waypoint_follow.py planner: the action recorded at step k was planned
     from the pose observed after step k-1."""
-    from red_gym_amd.planners import PurePursuitPlanner
+    from oracle.planner import PurePursuitPlanner
     conf = Namespace(**yaml.safe_load(open(os.path.join(assets, 'config_example_map.yaml'))))
     conf.wpt_path = os.path.join(assets, 'example_waypoints.csv')
     pl = PurePursuitPlanner(conf, 0.17145 + 0.15875)
@@ -113,3 +113,17 @@ def test_usable_cores():
     import bench
     n = bench.usable_cores()
     assert 1 <= n <= 64
+
+
+def test_map_name_resolution_matches_reference(assets):
+    """f110_env.py:106-118: berlin / skirk / levine are packaged; an explicit 'vegas' is ./vegas.yaml; only an
+    absent `map` keyword selects the packaged vegas.  'levine' ships no image (there as here): clear error."""
+    from red_gym_amd.vec_env import resolve_map_path
+    from red_gym_amd.maps import load_map
+    for name in ('berlin', 'skirk', 'levine'):
+        assert resolve_map_path(name) == os.path.join(assets, 'maps', name + '.yaml')
+    assert resolve_map_path('vegas') == 'vegas.yaml'
+    assert resolve_map_path('/tmp/some/track') == '/tmp/some/track.yaml'
+    assert resolve_map_path(None) == os.path.join(assets, 'maps', 'vegas.yaml')
+    with pytest.raises(FileNotFoundError, match='levine.png'):
+        load_map(resolve_map_path('levine'), '.png')
