@@ -18,6 +18,12 @@
  *     f110_step/f110_reset; kernels are enqueued on `stream` (a hipStream_t
  *     passed as void*, NULL = default stream) and the call does not synchronise.
  *   - a handle is bound to one device and is not thread-safe.
+ *   - there is no f110_get_state / f110_set_state: the whole simulation state lives in the CALLER-owned
+ *     buffers of the f110_buffers struct, bound once with f110_bind, so reading, checkpointing or overwriting the state is
+ *     an ordinary access to the caller's own memory between steps (F110VecEnv.state_dict / load_state_dict).
+ *   - tuning knobs read from the environment at first use (sweeps only; the defaults are the measured optimum):
+ *     F110_WPC = 1|2|4|8 wavefronts per car in the scan kernel; F110_STAGES = "cars:log2waves,..." wave -> car
+ *     stage list of a scan launch ("*" = the remaining cars), see launch_scan in csrc/f110_abi.hip.
  *   - all arithmetic that decides an index, a collision or a lap toggle is
  *     IEEE fp64 in the reference's operation order (no FMA contraction).
  */
@@ -222,6 +228,18 @@ int f110_check_ttc(f110_handle *h, const double *scans, const double *vel, int32
 int f110_ray_cast(f110_handle *h, const double *ego_poses, const double *opp_verts, int32_t n,
                   double *scans, int32_t *span, void *stream);
 
+/* F110Env._check_done (f110_env.py:202-244) on n envs of num_agents cars, stateless (h may be NULL):
+ * poses [n,A,3] (x, y, theta) and start_poses [n,A,3] (the poses given to reset: start_xs / start_ys, :321-323),
+ * start_rot [n,4] the EGO's 2x2 start rotation, row-major (:329), current_time [n] (already advanced by the
+ * step, :293), collisions [n,A] (only the ego's entry is read, :242).  In/out: near_start [n,A] (0/1, True after
+ * reset), toggles [n,A], lap_times [n,A] (frozen once a car has 4 toggles).  Out: lap_counts [n,A] = toggles // 2,
+ * done [n] = collisions[ego] or all(toggles >= 4), checkpoint_done [n,A] = toggles >= 4 (may be NULL).
+ * f110_step runs the same device function inside its env kernel. */
+int f110_check_done(f110_handle *h, const double *poses, const double *start_poses, const double *start_rot,
+                    const double *current_time, const uint8_t *collisions, int32_t n, int32_t num_agents,
+                    int32_t ego_idx, uint8_t *near_start, int32_t *toggles, int32_t *lap_counts, double *lap_times,
+                    uint8_t *done, uint8_t *checkpoint_done, void *stream);
+
 /* ---- scan -> bird's-eye bitmap (the first consumer of the step's scans) ----
  * Replaces weap_util/weap_util/lidar.py:105-154 `lidar_to_bitmap` (same body in src/SAL.py:274-395
  * and src/bitmap.py:4-140), which draws one scan with OpenCV 4.11 (fillPoly / polylines / line /
@@ -251,6 +269,11 @@ void f110_bitmap_destroy(f110_bitmap *b);
  * Enqueued on `stream`; no allocation, no synchronisation. */
 int f110_bitmap_render(f110_bitmap *b, const void *scans, int32_t scans_f64, int64_t n, int64_t stride,
                        uint8_t *out, void *stream);
+/* Function-level view of the renderer's first stage (parity tests): the integer points the reference computes
+ * at lidar.py:63-73 and hands to cv2.fillPoly / polylines / line -- points dev int32 [n, T, 2] = (x, y) of
+ * np.rint(center + scaling_factor * scan[indices] * {cos, sin}(angles)).astype(int), center = (rows//2, cols//2). */
+int f110_bitmap_points(f110_bitmap *b, const void *scans, int32_t scans_f64, int64_t n, int64_t stride,
+                       int32_t *points, void *stream);
 /* Point-occupancy grid of f1tenth_gym/examples/lidar.py:212-244 (the routine that wrote the
  * reference's lidar_datasets): out dev uint8 [n, grid, grid] of 0/1.  cosines / sines: dev [num_beams],
  * of np.linspace(-135, 135, num_beams) * pi / 180. */

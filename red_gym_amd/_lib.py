@@ -76,9 +76,11 @@ SYMBOLS = {
     'f110_collision_multiple': [_VP, _VP, _I32, _I32, _VP, _VP, _VP],
     'f110_check_ttc': [_VP, _VP, _VP, _I32, _VP, _VP],
     'f110_ray_cast': [_VP, _VP, _VP, _I32, _VP, _VP, _VP],
+    'f110_check_done': [_VP, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _VP, _VP, _VP, _VP, _VP, _VP, _VP],
     'f110_bitmap_create': [C.POINTER(BitmapConfig), _VP, _VP, _VP, C.POINTER(_VP)],
     'f110_bitmap_destroy': [_VP],
     'f110_bitmap_render': [_VP, _VP, _I32, _I64, _I64, _VP, _VP],
+    'f110_bitmap_points': [_VP, _VP, _I32, _I64, _I64, _VP, _VP],
     'f110_scan_occupancy': [_VP, _I32, _I64, _I64, _I32, _VP, _VP, _D, _D, _D, _I32, _VP, _VP],
 }
 

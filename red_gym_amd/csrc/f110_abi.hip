@@ -1063,6 +1063,27 @@ extern "C" int f110_ray_cast(f110_handle *h, const double *ego, const double *ve
     return F110_OK;
 }
 
+extern "C" int f110_check_done(f110_handle *h, const double *poses, const double *start_poses, const double *start_rot,
+                               const double *current_time, const uint8_t *collisions, int32_t n, int32_t num_agents,
+                               int32_t ego_idx, uint8_t *near_start, int32_t *toggles, int32_t *lap_counts,
+                               double *lap_times, uint8_t *done, uint8_t *checkpoint_done, void *stream)
+{
+    (void)h; // stateless (the strip width and the 0.1 threshold are constants of f110_env.py:216-231)
+    if (n < 0 || num_agents < 1 || num_agents > F110_MAX_AGENTS) return fail(F110_E_INVALID, "f110_check_done: bad arguments");
+    if (ego_idx < 0 || ego_idx >= num_agents) return fail(F110_E_INDEX, "f110_check_done: ego_idx %d out of range", ego_idx);
+    if (n == 0) return F110_OK;
+    if (!poses || !start_poses || !start_rot || !current_time || !collisions || !near_start || !toggles || !lap_counts ||
+        !lap_times || !done)
+        return fail(F110_E_INVALID, "f110_check_done: null pointer (only checkpoint_done is optional)");
+    CheckDoneArgs a;
+    a.n_envs = n; a.agents = num_agents; a.ego_idx = ego_idx; a.poses = poses; a.start = start_poses; a.start_rot = start_rot;
+    a.current_time = current_time; a.collisions = collisions; a.near_start = near_start; a.toggles = toggles;
+    a.lap_counts = lap_counts; a.lap_times = lap_times; a.done = done; a.checkpoint_done = checkpoint_done;
+    hipLaunchKernelGGL(check_done_kernel, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return F110_OK;
+}
+
 // ---------------------------------------------------------------- scan -> bitmap
 struct f110_bitmap {
     f110_bitmap_config cfg;
@@ -1132,6 +1153,24 @@ extern "C" int f110_bitmap_render(f110_bitmap *b, const void *scans, int32_t sca
     a.bg = b->cfg.bg_value; a.draw = b->cfg.draw_value; a.draw_center = b->cfg.draw_center;
     a.scale = b->cfg.scaling_factor; a.out = out; a.S = b->S;
     hipLaunchKernelGGL(bitmap_kernel, dim3((unsigned)n), dim3(BM_THREADS), b->lds, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return F110_OK;
+}
+
+extern "C" int f110_bitmap_points(f110_bitmap *b, const void *scans, int32_t scans_f64, int64_t n, int64_t stride,
+                                  int32_t *points, void *stream)
+{
+    if (!b || n < 0) return fail(F110_E_INVALID, "f110_bitmap_points: bad arguments");
+    if (n == 0) return F110_OK;
+    if (!scans || !points) return fail(F110_E_INVALID, "f110_bitmap_points: null pointer");
+    if (stride < b->cfg.num_beams || n > 0x7fffffff) return fail(F110_E_INVALID, "f110_bitmap_points: stride %lld < num_beams or n too large", (long long)stride);
+    BitmapArgs a;
+    memset(&a, 0, sizeof(a));
+    a.scans = scans; a.is_f64 = scans_f64 != 0; a.stride = stride; a.n = (int)n;
+    a.idx = b->d_idx; a.cosv = b->d_cos; a.sinv = b->d_sin; a.T = b->cfg.target_beam_count;
+    a.rows = b->cfg.rows; a.cols = b->cfg.cols; a.scale = b->cfg.scaling_factor;
+    const long long items = (long long)n * a.T;
+    hipLaunchKernelGGL(bitmap_points_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, points);
     HIP_TRY(hipGetLastError());
     return F110_OK;
 }

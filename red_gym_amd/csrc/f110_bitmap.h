@@ -209,6 +209,28 @@ __device__ inline unsigned bm_expand4(unsigned nib, unsigned cols2)
     return __builtin_amdgcn_perm(0u, cols2, sel);
 }
 
+// lidar.py:70-73: point k of image img = rint(center + (scaling_factor * data[k]) * {cos, sin}(angle k)).astype(int),
+// data = scan[indices] (:63-64); the integers the reference hands to cv2.fillPoly / polylines / line.
+__device__ inline int2 bm_point(const BitmapArgs &a, int img, int k, int cx, int cy)
+{
+    const long long o = (long long)img * a.stride + a.idx[k];
+    const double r = a.is_f64 ? static_cast<const double *>(a.scans)[o] : (double)static_cast<const float *>(a.scans)[o];
+    const double d = a.scale * r;
+    return make_int2((int)(long long)__builtin_rint((double)cx + d * a.cosv[k]),
+                     (int)(long long)__builtin_rint((double)cy + d * a.sinv[k]));
+}
+
+// function-level view of the point stage (f110_bitmap_points): out [n, T, 2] int32 (x, y)
+__global__ __launch_bounds__(256) void bitmap_points_kernel(BitmapArgs a, int *out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)a.n * a.T) return;
+    const int img = (int)(i / a.T), k = (int)(i % a.T);
+    const int2 p = bm_point(a, img, k, a.rows / 2, a.cols / 2);
+    out[2 * i] = p.x;
+    out[2 * i + 1] = p.y;
+}
+
 __global__ __launch_bounds__(BM_THREADS) void bitmap_kernel(BitmapArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
@@ -227,13 +249,7 @@ __global__ __launch_bounds__(BM_THREADS) void bitmap_kernel(BitmapArgs a)
 
     for (int i = tid; i < rows * S; i += BM_THREADS) anyp[i] = 0u;
     // lidar.py:70-81: points = rint(center + (scaling_factor * data) * {cos, sin}(angles)).astype(int)
-    for (int k = tid; k < T; k += BM_THREADS) {
-        const long long o = (long long)img * a.stride + a.idx[k];
-        const double r = a.is_f64 ? static_cast<const double *>(a.scans)[o] : (double)static_cast<const float *>(a.scans)[o];
-        const double d = a.scale * r;
-        pts[k] = make_int2((int)(long long)__builtin_rint((double)cx + d * a.cosv[k]),
-                           (int)(long long)__builtin_rint((double)cy + d * a.sinv[k]));
-    }
+    for (int k = tid; k < T; k += BM_THREADS) pts[k] = bm_point(a, img, k, cx, cy);
     __syncthreads();
 
     // ---- one record per segment: polygon edges pts[i-1] -> pts[i] (FILL, POLYGON) or rays centre -> pts[i]

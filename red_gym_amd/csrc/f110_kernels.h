@@ -654,6 +654,69 @@ __device__ inline void collision_multiple_dev(const double *poses /*[A,3]*/, int
     }
 }
 
+// F110Env._check_done (f110_env.py:202-244) for the A cars of one env: every car's offset from its OWN start
+// position, rotated by the EGO's start rotation (:219-221, :329), folded onto the 2 m wide start strip (:223-229),
+// `closes = dist2 <= 0.1` (:231), toggle on every change of near_start (:232-239), lap_counts = toggles // 2 (:238),
+// lap_times follows current_time while toggles < 4 (:239-240).  Returns all(toggles >= 4).
+// xy: car i's position at xy[i*stride], xy[i*stride+1]; start: [A,3] (x, y, theta).
+__device__ inline bool check_done_dev(const double *xy, int stride, const double *start, int A, double r00, double r01,
+                                      double r10, double r11, double current_time, uint8_t *near_start, int32_t *toggles,
+                                      int32_t *lap_counts, double *lap_times, uint8_t *checkpoint_done)
+{
+    const double left_t = 2, right_t = 2;
+    bool all_done = true;
+    for (int i = 0; i < A; i++) {
+        const double px = xy[(size_t)i * stride] - start[(size_t)i * 3];
+        const double py = xy[(size_t)i * stride + 1] - start[(size_t)i * 3 + 1];
+        const double dx = r00 * px + r01 * py;
+        double temp_y = r10 * px + r11 * py;
+        if (temp_y > left_t) temp_y -= left_t;
+        else if (temp_y < -right_t) temp_y = -right_t - temp_y;
+        else temp_y = 0;
+        const double dist2 = dx * dx + temp_y * temp_y;
+        const bool closes = dist2 <= 0.1;
+        bool ns = near_start[i] != 0;
+        int tg = toggles[i];
+        if (closes && !ns) { ns = true; tg += 1; }
+        else if (!closes && ns) { ns = false; tg += 1; }
+        near_start[i] = ns ? 1 : 0;
+        toggles[i] = tg;
+        lap_counts[i] = tg / 2;
+        if (tg < 4) lap_times[i] = current_time;
+        if (checkpoint_done) checkpoint_done[i] = tg >= 4 ? 1 : 0;
+        if (!(tg >= 4)) all_done = false;
+    }
+    return all_done;
+}
+
+// function-level _check_done: lane per env (f110_check_done)
+struct CheckDoneArgs {
+    int n_envs, agents, ego_idx;
+    const double *poses;        // [n,A,3]
+    const double *start;        // [n,A,3]
+    const double *start_rot;    // [n,4] row-major 2x2
+    const double *current_time; // [n]
+    const uint8_t *collisions;  // [n,A]
+    uint8_t *near_start;        // [n,A] in/out
+    int32_t *toggles;           // [n,A] in/out
+    int32_t *lap_counts;        // [n,A]
+    double *lap_times;          // [n,A] in/out
+    uint8_t *done;              // [n]
+    uint8_t *checkpoint_done;   // [n,A] or NULL
+};
+
+__global__ __launch_bounds__(128) void check_done_kernel(CheckDoneArgs a)
+{
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= a.n_envs) return;
+    const int A = a.agents, c0 = env * A;
+    const double *R = a.start_rot + (size_t)env * 4;
+    const bool all_done = check_done_dev(a.poses + (size_t)c0 * 3, 3, a.start + (size_t)c0 * 3, A, R[0], R[1], R[2], R[3],
+                                         a.current_time[env], a.near_start + c0, a.toggles + c0, a.lap_counts + c0,
+                                         a.lap_times + c0, a.checkpoint_done ? a.checkpoint_done + c0 : nullptr);
+    a.done[env] = ((a.collisions[c0 + a.ego_idx] != 0) || all_done) ? 1 : 0; // :242
+}
+
 __global__ __launch_bounds__(128) void env_kernel(EnvArgs a)
 {
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
@@ -689,31 +752,9 @@ __global__ __launch_bounds__(128) void env_kernel(EnvArgs a)
     }
     ct = ct + a.time_step; // f110_env.py:293
     a.current_time[env] = ct;
-    // _check_done (f110_env.py:202-244)
-    const double left_t = 2, right_t = 2;
-    bool all_done = true;
-    for (int i = 0; i < A; i++) {
-        const int car = c0 + i;
-        const double px = a.state[(size_t)car * 7] - a.spawn[(size_t)car * 3];
-        const double py = a.state[(size_t)car * 7 + 1] - a.spawn[(size_t)car * 3 + 1];
-        const double dx = r00 * px + r01 * py;
-        double temp_y = r10 * px + r11 * py;
-        if (temp_y > left_t) temp_y -= left_t;
-        else if (temp_y < -right_t) temp_y = -right_t - temp_y;
-        else temp_y = 0;
-        const double dist2 = dx * dx + temp_y * temp_y;
-        const bool closes = dist2 <= 0.1;
-        bool ns = a.near_start[car] != 0;
-        int tg = a.toggles[car];
-        if (closes && !ns) { ns = true; tg += 1; }
-        else if (!closes && ns) { ns = false; tg += 1; }
-        a.near_start[car] = ns ? 1 : 0;
-        a.toggles[car] = tg;
-        a.lap_counts[car] = tg / 2;
-        if (tg < 4) a.lap_times[car] = ct;
-        if (a.checkpoint_done) a.checkpoint_done[car] = tg >= 4 ? 1 : 0;
-        if (!(tg >= 4)) all_done = false;
-    }
+    const bool all_done = check_done_dev(a.state + (size_t)c0 * 7, 7, a.spawn + (size_t)c0 * 3, A, r00, r01, r10, r11, ct,
+                                         a.near_start + c0, a.toggles + c0, a.lap_counts + c0, a.lap_times + c0,
+                                         a.checkpoint_done ? a.checkpoint_done + c0 : nullptr);
     const bool dn = (a.collisions[c0 + a.ego_idx] != 0) || all_done;
     a.done[env] = dn ? 1 : 0;
     if (a.autoreset && dn) a.pending_reset[env] = 1;

@@ -374,3 +374,26 @@ def edt_squared(free_mask):
     out = np.empty(free_mask.shape, dtype=np.uint32)
     _lib.check(lib.f110_edt_squared(_np_ptr(free_mask), free_mask.shape[0], free_mask.shape[1], _np_ptr(out)))
     return out
+
+
+def check_done(poses, start_poses, start_rot, current_time, collisions, near_start, toggles, lap_times, ego_idx=0):
+    """F110Env._check_done (f110_env.py:202-244) through f110_check_done, for n envs of A cars.  Device tensors:
+    poses / start_poses [n,A,3] f64, start_rot [n,4] f64, current_time [n] f64, collisions [n,A] u8; near_start
+    [n,A] u8, toggles [n,A] i32 and lap_times [n,A] f64 are updated IN PLACE.  Returns (lap_counts [n,A] i32,
+    done [n] bool, checkpoint_done [n,A] bool)."""
+    lib = _lib.load()
+    n, A = poses.shape[0], poses.shape[1]
+    dev = poses.device
+    for t, dt in ((poses, torch.float64), (start_poses, torch.float64), (start_rot, torch.float64),
+                  (current_time, torch.float64), (collisions, torch.uint8), (near_start, torch.uint8),
+                  (toggles, torch.int32), (lap_times, torch.float64)):
+        if t.dtype != dt or not t.is_contiguous() or t.device != dev:
+            raise ValueError('check_done: tensors must be contiguous %s on %s' % (dt, dev))
+    lap_counts = torch.empty((n, A), dtype=torch.int32, device=dev)
+    done = torch.empty((n,), dtype=torch.bool, device=dev)
+    ckpt = torch.empty((n, A), dtype=torch.bool, device=dev)
+    _lib.check(lib.f110_check_done(None, _ptr(poses), _ptr(start_poses), _ptr(start_rot), _ptr(current_time),
+                                   _ptr(collisions), n, A, int(ego_idx), _ptr(near_start), _ptr(toggles),
+                                   _ptr(lap_counts), _ptr(lap_times), _ptr(done), _ptr(ckpt),
+                                   C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    return lap_counts, done, ckpt

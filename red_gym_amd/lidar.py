@@ -52,6 +52,7 @@ class LidarBitmap:
         self.lib = _lib.load()
         self.device = torch.device('cuda', device) if isinstance(device, int) else torch.device(device)
         self.num_beams, self.channels = int(num_beams), int(channels)
+        self.target_beam_count = int(target_beam_count)
         self.rows, self.cols = int(output_image_dims[0]), int(output_image_dims[1])
         idx, cs, sn = beam_tables(num_beams, target_beam_count, winding_dir, starting_angle, fov)
         cfg = _lib.BitmapConfig(device=self.device.index or 0, num_beams=num_beams,
@@ -86,6 +87,21 @@ class LidarBitmap:
         _lib.check(self.lib.f110_bitmap_render(self.h, s.data_ptr(), int(s.dtype == torch.float64), n,
                                                s.stride(0) if n > 1 else self.num_beams, out.data_ptr(), stream))
         out = out.reshape(scans.shape[:-1] + shape[1:]) if not single else out[0]
+        return out
+
+    def points(self, scans):
+        """The integer points of lidar.py:63-73 (what the reference passes to the cv2 draw calls):
+        [N, target_beam_count, 2] int32 device tensor of (x, y)."""
+        s = scans.reshape(-1, scans.shape[-1])
+        if s.dtype not in (torch.float32, torch.float64):
+            s = s.to(torch.float64)
+        s = s.to(self.device).contiguous()
+        n = s.shape[0]
+        out = torch.empty((n, self.target_beam_count, 2), dtype=torch.int32, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(self.lib.f110_bitmap_points(self.h, s.data_ptr(), int(s.dtype == torch.float64), n, s.stride(0),
+                                               out.data_ptr(), stream))
+        torch.cuda.current_stream(self.device).synchronize()  # `s` may be a temporary
         return out
 
     def close(self):

@@ -161,3 +161,50 @@ def test_bitmap_fuzz_random_options():
         got = r(torch.as_tensor(scans, device='cuda')).cpu().numpy()
         assert np.array_equal(got, want), (trial, opts)
         r.close()
+
+
+def test_point_stage_equals_reference_draw_calls(golden):
+    """The kernel's point stage (f110_bitmap_points, the same device function bitmap_kernel starts with) against
+    the integers the reference handed to cv2.fillPoly / polylines / line (g10: weap_util/weap_util/lidar.py run with
+    a recording cv2): beam subset, angle table, scaling, rint -- `==` for 48 scans x 8 option sets, f64 scans.
+    The rasterisation of those points stays pinned only to the OpenCV restatement (parity unpinned)."""
+    import json
+    from red_gym_amd.lidar import LidarBitmap
+    g = golden('g10_bitmap_calls.npz')
+    grid = json.loads(str(g['options']))
+    scans = torch.as_tensor(g['scans'], device='cuda')
+    off, val = g['arg_off'], g['arg_val']
+    for oi, opt in enumerate(grid):
+        r = LidarBitmap(1080, **opt)
+        pts = r.points(scans).cpu().numpy()
+        T = opt.get('target_beam_count', 600)
+        sel = np.flatnonzero(g['opt_id'] == oi)
+        seen = 0
+        for si in range(scans.shape[0]):
+            calls = sel[g['scan_id'][sel] == si]
+            if opt['draw_mode'] == 'RAYS':
+                lines = [i for i in calls if g['op'][i] == 2]
+                ref = np.array([val[off[i] + 2:off[i] + 4] for i in lines])    # cv2.line(center, p)
+            else:
+                i = calls[0]
+                assert g['op'][i] in (0, 1)
+                ref = val[off[i]:off[i + 1]].reshape(-1, 2)
+            assert ref.shape == (T, 2) and np.array_equal(pts[si], ref), (oi, si)
+            seen += 1
+        assert seen == scans.shape[0]
+        r.close()
+
+
+def test_occupancy_kernel_equals_reference_dataset(golden):
+    """occupancy_kernel against the dataset the reference's f1tenth_gym/examples/lidar.py main() produced in the
+    dev container (g12: its own scans, its own (N,256,256) uint8 array): `==`, f64 and f32 scans."""
+    from red_gym_amd.lidar import scan_occupancy
+    g = golden('g12_pointgrid.npz')
+    shape = tuple(g['shape'])
+    data = np.unpackbits(g['data_bits'], axis=-1)[..., :shape[-1]].reshape(shape)
+    scans = torch.as_tensor(g['scans'], device='cuda')
+    got = scan_occupancy(scans).cpu().numpy()
+    assert got.dtype == np.uint8 and np.array_equal(got, data)
+    # fp32 scans (what f110_step writes): identical unless a point sits within fp32 rounding of a cell edge
+    got32 = scan_occupancy(scans.float()).cpu().numpy()
+    assert (got32 != data).mean() < 1e-4

@@ -350,3 +350,91 @@ def test_checkpoint_resume(assets):
     assert torch.equal(e1.state, e2.state) and torch.equal(obs1['scans'], obs2['scans']) and torch.equal(d1, d2)
     assert torch.equal(e1.eng.t['toggles'], e2.eng.t['toggles']) and torch.equal(e1.eng.t['lap_times'], e2.eng.t['lap_times'])
     e1.close(); e2.close()
+
+
+def test_env_closed_loop_two_agents_golden(golden, assets):
+    """Two cars, both on the reference planner's recorded actions, until all(toggles >= 4) (g9, generated by the
+    reference's F110Env): _check_done with A > 1 -- the ego's start rotation applied to every car
+    (f110_env.py:219-221), lap counts, lap times frozen at 4 toggles while the other car keeps driving, done only
+    through all() -- every flag `==` at every step."""
+    from red_gym_amd import F110Env, Integrator
+    g = golden('g9_env2.npz')
+    env = F110Env(map=os.path.join(assets, 'example_map'), map_ext='.png', num_agents=2, timestep=0.01,
+                  integrator=Integrator.RK4)
+    obs, r, done, info = env.reset(g['start'])
+    assert np.allclose(np.array([obs['poses_x'], obs['poses_y'], obs['poses_theta']]).T, g['reset_obs'], atol=1e-12)
+    T = g['actions'].shape[0]
+    scan_at = dict(zip(g['scan_steps'].tolist(), g['scans']))
+    for k in range(T):
+        obs, r, done, info = env.step(g['actions'][k])
+        assert np.allclose(obs['poses_x'], g['x'][k], rtol=0, atol=1e-7) and np.allclose(obs['poses_y'], g['y'][k], rtol=0, atol=1e-7), k
+        assert np.allclose(obs['poses_theta'], g['theta'][k], rtol=0, atol=1e-7), k
+        assert np.array_equal(obs['collisions'], g['col'][k]), k
+        assert np.array_equal(env.toggle_list, g['toggle'][k]), k
+        assert np.array_equal(obs['lap_counts'], g['lap_c'][k]) and np.array_equal(obs['lap_times'], g['lap_t'][k]), k
+        assert done == bool(g['done'][k]) and np.array_equal(info['checkpoint_done'], g['ckpt'][k]), k
+        if k in scan_at:
+            assert np.allclose(np.stack(obs['scans']), scan_at[k], rtol=0, atol=1e-7), k
+    tg = g['toggle']
+    # the run really exercises what it is for: both cars complete two laps, at different times, without the ego
+    # colliding, and the first finisher's lap time stays frozen while its toggles go on
+    assert (tg[-1] >= 4).all() and bool(g['done'][-1]) and not g['done'][:-1].any()
+    first = int(np.argmax((tg >= 4).any(axis=1)))
+    assert first < T - 50 and (g['lap_t'][first:, np.argmax(tg[first] >= 4)] == g['lap_t'][first, np.argmax(tg[first] >= 4)]).all()
+    env.close()
+
+
+def _check_done_replay(x, y, theta, start, col, time, ego_idx=0):
+    """Feeds a recorded pose sequence [T,A] step by step to f110_check_done (state carried on the device)."""
+    import torch
+    from red_gym_amd.engine import check_done
+    T, A = x.shape
+    dev = torch.device('cuda', 0)
+    poses = torch.as_tensor(np.stack([x, y, theta], axis=-1).reshape(T, 1, A, 3), device=dev).contiguous()
+    st = torch.as_tensor(np.ascontiguousarray(start, dtype=np.float64).reshape(1, A, 3), device=dev)
+    th = -start[ego_idx][2]   # f110_env.py:329, numpy like the reference
+    rot = torch.as_tensor(np.array([[np.cos(th), -np.sin(th), np.sin(th), np.cos(th)]]), device=dev)
+    cols = torch.as_tensor(np.ascontiguousarray(col, dtype=np.uint8).reshape(T, 1, A), device=dev)
+    times = torch.as_tensor(np.ascontiguousarray(time, dtype=np.float64).reshape(T, 1), device=dev)
+    near = torch.ones((1, A), dtype=torch.uint8, device=dev)
+    tog = torch.zeros((1, A), dtype=torch.int32, device=dev)
+    lapt = torch.zeros((1, A), dtype=torch.float64, device=dev)
+    out = {k: [] for k in ('toggle', 'lap_c', 'lap_t', 'done', 'ckpt', 'near')}
+    for k in range(T):
+        lc, dn, ck = check_done(poses[k], st, rot, times[k], cols[k], near, tog, lapt, ego_idx)
+        for key, t in (('toggle', tog), ('lap_c', lc), ('lap_t', lapt), ('done', dn), ('ckpt', ck), ('near', near)):
+            out[key].append(t.clone())
+    return {k: torch.stack(v).cpu().numpy().reshape(T, -1) for k, v in out.items()}
+
+
+def test_check_done_function_level_golden(golden):
+    """f110_check_done (f110_env.py:202-244) on the reference's recorded poses: the 1-agent 2-lap run (g8) and
+    the 2-agent run to all(toggles >= 4) (g9); toggles, lap counts, lap times, done, checkpoint_done `==`."""
+    g = golden('g8_env.npz')
+    T = g['x'].shape[0]
+    times = np.cumsum(np.full(T + 1, 0.01))[1:]  # current_time after reset's own step and k+1 steps (:293), same additions
+    r = _check_done_replay(g['x'][:, None], g['y'][:, None], g['theta'][:, None], g['start'], g['col'][:, None], times)
+    assert np.array_equal(r['toggle'][:, 0], g['toggle']) and np.array_equal(r['lap_c'][:, 0], g['lap_c'])
+    assert np.array_equal(r['lap_t'][:, 0], g['lap_t']) and np.array_equal(r['done'][:, 0], g['done'].astype(bool))
+    g = golden('g9_env2.npz')
+    r = _check_done_replay(g['x'], g['y'], g['theta'], g['start'], g['col'], g['time'])
+    assert np.array_equal(r['toggle'], g['toggle']) and np.array_equal(r['lap_c'], g['lap_c'])
+    assert np.array_equal(r['lap_t'], g['lap_t']) and np.array_equal(r['done'][:, 0], g['done'].astype(bool))
+    assert np.array_equal(r['ckpt'], g['ckpt']) and np.array_equal(r['near'].astype(bool), g['near'])
+    # a different ego: the rotation and the collision entry of car 1 are used (done fires when car 1 collides)
+    col = np.zeros_like(g['col']); col[5, 1] = 1
+    r1 = _check_done_replay(g['x'][:20], g['y'][:20], g['theta'][:20], g['start'], col[:20], g['time'][:20], ego_idx=1)
+    assert r1['done'][:, 0].tolist() == [k == 5 for k in range(20)]
+
+
+def test_check_done_argument_errors():
+    import torch
+    from red_gym_amd.engine import check_done
+    dev = torch.device('cuda', 0)
+    z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)  # noqa: E731
+    args = [z((2, 2, 3), torch.float64), z((2, 2, 3), torch.float64), z((2, 4), torch.float64), z((2,), torch.float64),
+            z((2, 2), torch.uint8), z((2, 2), torch.uint8), z((2, 2), torch.int32), z((2, 2), torch.float64)]
+    with pytest.raises(IndexError):
+        check_done(*args, ego_idx=2)
+    with pytest.raises(ValueError):
+        check_done(*(args[:6] + [z((2, 2), torch.int64), args[7]]))

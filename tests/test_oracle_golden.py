@@ -258,3 +258,24 @@ def test_env_closed_loop_golden(golden, assets):
         if k in scan_at:
             assert np.allclose(o['scans'][0], scan_at[k], rtol=0, atol=1e-7), k
     assert o['done'] and o['lap_counts'][0] == 2 and o['current_time'] == g['final_time']
+
+
+def test_env_closed_loop_two_agents_golden(golden, assets):
+    """The oracle's _check_done with A > 1 pinned by the reference's own 2-agent run to all(toggles >= 4) (g9):
+    the ego's start rotation on every car (f110_env.py:219-221), frozen lap times, done only through all()."""
+    g = golden('g9_env2.npz')
+    T = g['actions'].shape[0]
+    env = _mk_env(assets, 2, T + 2)
+    o = env.reset(g['start'])
+    assert np.allclose(o['state'][:, [0, 1, 4]], g['reset_obs'], atol=1e-12)
+    scan_at = dict(zip(g['scan_steps'].tolist(), g['scans']))
+    for k in range(T):
+        o = env.step(g['actions'][k])
+        assert np.allclose(o['state'][:, 0], g['x'][k], rtol=0, atol=1e-7) and np.allclose(o['state'][:, 1], g['y'][k], rtol=0, atol=1e-7), k
+        assert np.array_equal(o['collisions'], g['col'][k]), k
+        assert np.array_equal(o['toggles'], g['toggle'][k]), k
+        assert np.array_equal(o['lap_counts'], g['lap_c'][k]) and np.array_equal(o['lap_times'], g['lap_t'][k]), k
+        assert o['done'] == bool(g['done'][k]), k
+        if k in scan_at:
+            assert np.allclose(o['scans'], scan_at[k], rtol=0, atol=1e-7), k
+    assert o['done'] and (g['toggle'][-1] >= 4).all() and g['toggle'][-1].max() >= 5
