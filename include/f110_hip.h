@@ -181,6 +181,13 @@ int f110_reset(f110_handle *h, const double *poses_dev, const uint8_t *mask_dev,
  * ignore their action and perform reset(spawn) + zero-action step instead. */
 int f110_step(f110_handle *h, const double *actions_dev, void *stream);
 
+/* hipGraph support.  f110_step only enqueues kernels (no allocation, no synchronisation), so it can be captured
+ * into a HIP graph and replayed.  A capture freezes the kernel selection and the by-value launch arguments; the
+ * calls that change them -- f110_bind, f110_set_tables, f110_set_noise_table (the table is re-allocated), every map
+ * install, f110_assign_maps -- bump the handle's launch epoch.  A graph captured at epoch e is valid while
+ * f110_launch_epoch still reports e; after that it must be re-captured (F110VecEnv.step_graph does so itself). */
+int f110_launch_epoch(f110_handle *h, int64_t *epoch);
+
 /* Measurement aid (bench.py): between begin and end every f110_step attaches a start / stop
  * hipEvent pair to its scan_kernel dispatch on the step's stream (up to max_launches
  * steps).  f110_profile_end synchronises on the last event and returns the summed

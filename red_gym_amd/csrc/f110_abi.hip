@@ -47,6 +47,9 @@ struct f110_handle {
     Params *d_agent_params = nullptr;
     OppPair *d_opp_pairs = nullptr;   // [N, A-1] opponent ray-cast scratch
     bool has_map = false, bound = false;
+    // Bumped whenever a later f110_step would enqueue different kernels or by-value arguments than an earlier one
+    // (a table re-allocated, another scan instantiation selected, buffers re-bound): f110_launch_epoch.
+    int64_t epoch = 0;
     f110_buffers bufs;
     // device tables owned by the handle
     double *d_scan_angles = nullptr, *d_beam_cosines = nullptr, *d_side = nullptr;
@@ -342,6 +345,7 @@ extern "C" int f110_set_tables(f110_handle *h, const double *sines, const double
     if ((sines || cosines) && (rc = upload_cs(h))) return rc;
     if (ang && ((rc = upload(&h->d_scan_angles, ang, h->cfg.num_beams)) || (rc = upload_beam_cs(h, ang)))) return rc;
     if (bcos && (rc = upload(&h->d_beam_cosines, bcos, h->cfg.num_beams))) return rc;
+    h->epoch++;
     if (side) {
         if ((rc = upload(&h->d_side, side, h->cfg.num_beams))) return rc;
         h->h_side.assign(side, side + h->cfg.num_beams);
@@ -375,6 +379,7 @@ static int finish_map(f110_handle *h, int slot, int H, int W, int Hp, size_t n_t
     for (const auto &u : h->slots)
         if (u.used) { h->ident = h->ident && u.ident; h->pow2 = h->pow2 && u.pow2; }
     h->has_map = h->slots[0].used;
+    h->epoch++;
     return F110_OK;
 }
 
@@ -676,6 +681,7 @@ extern "C" int f110_assign_maps(f110_handle *h, const int32_t *map_of_env)
     HIP_TRY(hipMemcpy(h->d_env_map, m.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice));
     h->h_env_map = m;
     h->multi = multi;
+    h->epoch++;
     return F110_OK;
 }
 
@@ -708,6 +714,7 @@ static int rebuild_noise_side(f110_handle *h)
     HIP_TRY(hipMalloc((void **)&h->d_noise_side, ns.size() * sizeof(double2)));
     HIP_TRY(hipMemcpy(h->d_noise_side, ns.data(), ns.size() * sizeof(double2), hipMemcpyHostToDevice));
     h->noise_T = T;
+    h->epoch++;
     return F110_OK;
 }
 
@@ -722,6 +729,7 @@ extern "C" int f110_bind(f110_handle *h, const f110_buffers *b)
         if (!p) return fail(F110_E_INVALID, "f110_bind: a required buffer is NULL (only scans_f64, checkpoint_done and lookups are optional)");
     h->bufs = *b;
     h->bound = true;
+    h->epoch++;
     return F110_OK;
 }
 
@@ -742,10 +750,18 @@ static int launch_scan_t(f110_handle *h, const ScanArgs &a, hipStream_t st, hipE
     int waves = 0;
     for (int i = 0; i < a.n_stages; i++) waves += a.stage_cars[i] << a.stage_log2w[i];
     const dim3 grid((waves + SCAN_WAVES - 1) / SCAN_WAVES), block(SCAN_THREADS);
-    if (h->ident && h->pow2) hipExtLaunchKernelGGL((scan_kernel<true, true, STEP>), grid, block, 0, st, ev0, ev1, 0, a);
-    else if (h->ident) hipExtLaunchKernelGGL((scan_kernel<true, false, STEP>), grid, block, 0, st, ev0, ev1, 0, a);
-    else if (h->pow2) hipExtLaunchKernelGGL((scan_kernel<false, true, STEP>), grid, block, 0, st, ev0, ev1, 0, a);
-    else hipExtLaunchKernelGGL((scan_kernel<false, false, STEP>), grid, block, 0, st, ev0, ev1, 0, a);
+    // plain launches unless the measurement aid attached events (hipExtLaunchKernelGGL is only needed for those;
+    // a captured hipGraph then holds ordinary kernel nodes)
+#define F110_SCAN_LAUNCH(I, P)                                                                                     \
+    do {                                                                                                           \
+        if (ev0 || ev1) hipExtLaunchKernelGGL((scan_kernel<I, P, STEP>), grid, block, 0, st, ev0, ev1, 0, a);       \
+        else hipLaunchKernelGGL((scan_kernel<I, P, STEP>), grid, block, 0, st, a);                                  \
+    } while (0)
+    if (h->ident && h->pow2) F110_SCAN_LAUNCH(true, true);
+    else if (h->ident) F110_SCAN_LAUNCH(true, false);
+    else if (h->pow2) F110_SCAN_LAUNCH(false, true);
+    else F110_SCAN_LAUNCH(false, false);
+#undef F110_SCAN_LAUNCH
     HIP_TRY(hipGetLastError());
     return F110_OK;
 }
@@ -908,6 +924,13 @@ extern "C" int f110_step(f110_handle *h, const double *actions, void *stream)
     if (rc) return rc;
     if (!actions) return fail(F110_E_INVALID, "f110_step: null actions");
     return run_step(h, actions, 0, (hipStream_t)stream);
+}
+
+extern "C" int f110_launch_epoch(f110_handle *h, int64_t *epoch)
+{
+    if (!h || !epoch) return fail(F110_E_INVALID, "f110_launch_epoch: null argument");
+    *epoch = h->epoch;
+    return F110_OK;
 }
 
 // ---------------------------------------------------------------- measurement aid

@@ -146,7 +146,11 @@ __device__ inline double dist_lookup(const MapView &m, const double *lds_lut, do
     // a finished ray presents an out-of-range offset: the hardware range check answers 0
     // (= LDS offset 0 = distance 0.0, which parks the ray: total += 0, x += 0*c) without
     // occupying the L1 tag pipeline
+#if !defined(F110_NO_PARK)
     off = live ? off : 0xffffffffu;
+#else
+    (void)live; // variant: finished rays keep reading their last cell (d = 0 there, or total already past max_range)
+#endif
     // buffer load: 32-bit per-lane offset against a scalar descriptor
     const unsigned code = (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(m.cells_rsrc, (int)off, 0, 0);
     // common case: the loaded value IS the LDS byte offset of the distance: one ds_read_b64
@@ -378,6 +382,9 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
                 const double2 cs = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(a.scan.cs) + (size_t)((unsigned)ti * 16u)); // second round trip, overlapped with emit()
                 if (beam >= 0) emit(beam, total, nzv, sdv);
                 beam = -1;
+#if defined(F110_NO_PARK)
+                total = __builtin_inf(); // a lane without a ray must stay inactive (total <= max_range fails)
+#endif
                 if (take) {
                     c = cs.x;
                     s = cs.y;

@@ -345,6 +345,12 @@ class Engine(object):
         self._keep_wp = waypoints
         return out.view(self.B, self.A, 2) if state is None else out
 
+    def launch_epoch(self):
+        """Changes whenever a captured hipGraph of step() has gone stale (f110_launch_epoch)."""
+        e = C.c_int64(0)
+        _lib.check(self.lib.f110_launch_epoch(self._h, C.byref(e)))
+        return e.value
+
     # ------------------------------------------------------------------ measurement aid
     def profile_begin(self, max_launches):
         _lib.check(self.lib.f110_profile_begin(self._h, int(max_launches)))

@@ -29,7 +29,8 @@ def resolve_map_path(map_name):
 class F110VecEnv(object):
     def __init__(self, num_envs, map=None, map_ext='.png', params=None, num_agents=2, timestep=0.01,
                  ego_idx=0, integrator=Integrator.RK4, fov=2 * np.pi, seed=12345, device=0, autoreset=True,
-                 num_beams=1080, noise_std=0.01, keep_f64_scans=False, count_lookups=False, **_ignored):
+                 num_beams=1080, noise_std=0.01, noise_steps=4096, keep_f64_scans=False, count_lookups=False,
+                 **_ignored):
         self.num_envs, self.num_agents = int(num_envs), int(num_agents)
         self.map_name, self.map_ext = map, map_ext
         self.map_path = resolve_map_path(map)
@@ -37,7 +38,7 @@ class F110VecEnv(object):
         self.timestep, self.ego_idx, self.seed = timestep, ego_idx, seed
         self.eng = Engine(num_envs=num_envs, num_agents=num_agents, params=self.params, seed=seed, fov=fov,
                           timestep=timestep, integrator=integrator, ego_idx=ego_idx, num_beams=num_beams,
-                          device=device, autoreset=autoreset, noise_std=noise_std,
+                          device=device, autoreset=autoreset, noise_std=noise_std, noise_steps=noise_steps,
                           keep_f64_scans=keep_f64_scans, count_lookups=count_lookups)
         self.eng.set_map(self.map_path, self.map_ext)
         self.device = self.eng.device
@@ -113,8 +114,11 @@ class F110VecEnv(object):
         action buffer, e.g. `lambda env, out: env.eng.pure_pursuit(wp, tlad, vgain, out=out)`)
         into a HIP graph.  f110_step neither allocates nor synchronises, so the three or four
         kernel launches replay from one graph launch; `step_graph()` then costs one host call.
-        Returns the static action buffer [B,A,2] to write into when no policy is given."""
-        self._g_actions = torch.zeros((self.num_envs, self.num_agents, 2), dtype=torch.float64, device=self.device)
+        Returns the static action buffer [B,A,2] to write into when no policy is given (it stays the
+        same tensor across re-captures)."""
+        if getattr(self, '_g_actions', None) is None:
+            self._g_actions = torch.zeros((self.num_envs, self.num_agents, 2), dtype=torch.float64, device=self.device)
+        self._g_policy = policy
         self.eng._grow_noise_if_needed()
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
@@ -127,12 +131,21 @@ class F110VecEnv(object):
         torch.cuda.current_stream(self.device).wait_stream(side)
         # the capture itself did not execute anything; undo its host-side step accounting
         self.eng.host_steps_bound -= 1
+        # a capture freezes the kernel choice and the by-value arguments (noise table address and length, map
+        # template flags, env -> map table): it is valid for this launch epoch only
+        self._g_epoch = self.eng.launch_epoch()
         return self._g_actions
 
     def step_graph(self, actions=None):
+        """Replays the captured step.  With `actions` they are copied into the static buffer first; cheaper is to
+        write into the buffer capture_step returned (or to capture a policy).  If the handle's launch epoch moved
+        since the capture (the noise table grew, a map with other template flags was installed, tracks were
+        randomised) the step is re-captured first, so a replay never reads a freed table."""
         if actions is not None:
             self._g_actions.copy_(self._as_dev(actions, 2))
         self.eng._grow_noise_if_needed()
+        if self.eng.launch_epoch() != self._g_epoch:
+            self.capture_step(self._g_policy)
         self._graph.replay()
         self.eng.host_steps_bound += 1
         return self._result()

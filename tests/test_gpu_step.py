@@ -280,6 +280,40 @@ def test_hipgraph_replay_equals_eager(assets):
     e1.close(); e2.close()
 
 
+def test_hipgraph_survives_table_changes(assets):
+    """A captured step freezes the noise table's address / length, the scan instantiation and the env -> map
+    table.  The noise table is re-allocated when a car outlives it (here: 8 rows), and update_map can switch
+    the instantiation (berlin: resolution 0.05, not a power of two): step_graph must notice (launch epoch) and
+    re-capture instead of replaying against freed memory.  Scans, state and noise rows `==` eager stepping."""
+    import torch
+    from red_gym_amd import workload
+    B = 64
+    poses = workload.spawn_poses(B, 1)
+    acts = torch.as_tensor(workload.action_pool(8, B, 1) * np.array([1.0, 0.25]), device='cuda')  # slow: nobody crashes early
+    e1, e2 = _vec(assets, B, 1, noise_steps=8), _vec(assets, B, 1, noise_steps=8)
+    e1.reset(poses); e2.reset(poses)
+    buf = e2.capture_step()
+    ep0 = e2.eng.launch_epoch()
+    rows0 = e2.eng._noise_dev_rows
+    for k in range(40):                       # 41 scans per car: the table has to grow 8 -> 16 -> 32 -> 64
+        e1.step(acts[k % 8])
+        buf.copy_(acts[k % 8])
+        e2.step_graph()
+        assert torch.equal(e1.eng.t['scans_f64'], e2.eng.t['scans_f64']), k
+    assert e2.eng._noise_dev_rows > rows0 and e2.eng.launch_epoch() > ep0
+    assert torch.equal(e1.state, e2.state) and int(e2.eng.t['noise_step'].min()) >= 30
+    # another map with another scan instantiation, then back
+    for y in (os.path.join(assets, 'maps', 'berlin.yaml'), os.path.join(assets, 'example_map.yaml')):
+        e1.update_map(y, '.png'); e2.update_map(y, '.png')
+        p = np.zeros((B, 1, 3)) if 'berlin' in y else poses
+        e1.reset(p); e2.reset(p)
+        for k in range(3):
+            e1.step(acts[k])
+            e2.step_graph(acts[k])
+            assert torch.equal(e1.eng.t['scans_f64'], e2.eng.t['scans_f64']), (y, k)
+    e1.close(); e2.close()
+
+
 @pytest.mark.parametrize('cfg', [
     dict(map='maps/berlin', fov=4.7, num_beams=1080, A=2, ego_idx=1, integ='RK4'),      # res 0.05: guarded-reciprocal index path
     dict(map='maps/skirk', fov=2 * np.pi, num_beams=271, A=1, ego_idx=0, integ='Euler'),  # odd beam count (partial chunk)

@@ -1,19 +1,34 @@
+"""Eager launches vs hipGraph replay of the step, with the pieces that could explain a gap separated:
+    python tools/graph_vs_eager.py [mode ...]     modes: eager graph_copy graph_nocopy   (default: all)
+Run one mode under `rocprofv3 --kernel-trace` and feed the trace to tools/trace_gaps.py to see kernel
+durations and the idle gaps between consecutive dispatches."""
 import os, sys, time
-sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
+sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from red_gym_amd import F110VecEnv, workload
-for B in (65536, 4096):
+modes = [m for m in sys.argv[1:] if not m.isdigit()] or ['eager', 'graph_copy', 'graph_nocopy']
+sizes = [int(m) for m in sys.argv[1:] if m.isdigit()] or [65536, 4096]
+N = 200
+for B in sizes:
     env = F110VecEnv(B, map=workload.EXAMPLE_MAP, num_agents=1, autoreset=True)
     env.reset(torch.as_tensor(workload.spawn_poses(B, 1), device=env.device))
     acts = torch.as_tensor(workload.action_pool(8, B, 1), device=env.device)
     for k in range(30): env.step(acts[k % 8])
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for k in range(200): env.step(acts[k % 8])
-    torch.cuda.synchronize(); eager = (time.perf_counter() - t0) / 200
-    buf = env.capture_step()
-    for k in range(10): env.step_graph(acts[k % 8])
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for k in range(200): env.step_graph(acts[k % 8])
-    torch.cuda.synchronize(); graph = (time.perf_counter() - t0) / 200
-    print(B, 'eager %.4f ms  graph %.4f ms' % (eager * 1e3, graph * 1e3))
+    res = {}
+    if 'eager' in modes:
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for k in range(N): env.step(acts[k % 8])
+        torch.cuda.synchronize(); res['eager'] = (time.perf_counter() - t0) / N
+    if 'graph_copy' in modes or 'graph_nocopy' in modes:
+        buf = env.capture_step()
+        for k in range(10): env.step_graph(acts[k % 8])
+    if 'graph_copy' in modes:
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for k in range(N): env.step_graph(acts[k % 8])
+        torch.cuda.synchronize(); res['graph_copy'] = (time.perf_counter() - t0) / N
+    if 'graph_nocopy' in modes:       # actions already sit in the static buffer
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for k in range(N): env.step_graph()
+        torch.cuda.synchronize(); res['graph_nocopy'] = (time.perf_counter() - t0) / N
+    print(B, '  '.join('%s %.4f ms' % (k, v * 1e3) for k, v in res.items()), flush=True)
     env.close()
