@@ -181,6 +181,12 @@ int f110_reset(f110_handle *h, const double *poses_dev, const uint8_t *mask_dev,
  * ignore their action and perform reset(spawn) + zero-action step instead. */
 int f110_step(f110_handle *h, const double *actions_dev, void *stream);
 
+/* Tuning / test hook: how a scan launch maps wavefronts to cars, as "cars:lg,cars:lg,..." in launch order with one
+ * "*" for the remaining cars: a car of a stage gets 2^lg wavefronts (lg = 0..3; several short-lived waves per car pay
+ * for small batches and at the end of a launch).  NULL or "" restores the built-in choice (or the F110_STAGES
+ * environment variable).  Results do not depend on it. */
+int f110_set_scan_stages(f110_handle *h, const char *spec);
+
 /* hipGraph support.  f110_step only enqueues kernels (no allocation, no synchronisation), so it can be captured
  * into a HIP graph and replayed.  A capture freezes the kernel selection and the by-value launch arguments; the
  * calls that change them -- f110_bind, f110_set_tables, f110_set_noise_table (the table is re-allocated), every map

@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <string>
 #include <utility>
 #include <vector>
 
@@ -50,6 +51,7 @@ struct f110_handle {
     // Bumped whenever a later f110_step would enqueue different kernels or by-value arguments than an earlier one
     // (a table re-allocated, another scan instantiation selected, buffers re-bound): f110_launch_epoch.
     int64_t epoch = 0;
+    std::string stages;               // f110_set_scan_stages override ("" = F110_STAGES or the built-in choice)
     f110_buffers bufs;
     // device tables owned by the handle
     double *d_scan_angles = nullptr, *d_beam_cosines = nullptr, *d_side = nullptr;
@@ -794,12 +796,16 @@ static int launch_scan(f110_handle *h, const ScanArgs &a_in, hipStream_t st, hip
     // 4 096: 0.126 -> 0.105 with half of the cars split; graded tails (halves, quarters, eighths) and graded
     // heads changed nothing.  F110_STAGES="cars:log2waves,..." with one "*" for the remaining cars overrides
     // the choice below (e.g. "*:0,2048:2" is the default for big launches).
-    static const char *stages_env = getenv("F110_STAGES");
+    // (Measured and dropped in round 2, profiles/r02_multicar_waves_sweep.txt: stages that give one wave K = 2, 4, 8
+    // consecutive cars to march back to back, so that a wave drains once per K cars -- 0.705 ms at best against
+    // 0.664 ms: the leaner refill of one car per wave and the finer-grained launch win.)
+    static const char *stages_env0 = getenv("F110_STAGES");
+    const char *stages_env = h->stages.empty() ? stages_env0 : h->stages.c_str();
     const int nch = (a.scan.nb + 63) / 64;
     int lg_all = a.wpc >= 8 ? 3 : a.wpc >= 4 ? 2 : a.wpc >= 2 ? 1 : 0;
     struct St { int cars, lg; };
     std::vector<St> stv;
-    if (lg_all > 0 || nch < 8) stv.push_back({a.n_cars, lg_all});
+    if (h->stages.empty() && (lg_all > 0 || nch < 8)) stv.push_back({a.n_cars, lg_all});
     else {
         std::vector<St> spec;
         if (stages_env) {
@@ -817,7 +823,7 @@ static int launch_scan(f110_handle *h, const ScanArgs &a_in, hipStream_t st, hip
         }
         int fixed = 0;
         for (auto &x : spec) if (x.cars >= 0) { x.cars -= x.cars % SCAN_WAVES; fixed += x.cars; }
-        if (fixed > a.n_cars || spec.size() > 8) { spec = {{-1, 0}}; fixed = 0; }
+        if (fixed > a.n_cars || spec.size() > 6) { spec = {{-1, 0}}; fixed = 0; }
         bool star = false;
         for (auto &x : spec) if (x.cars < 0 && !star) { x.cars = a.n_cars - fixed; star = true; }
         if (!star) spec.push_back({a.n_cars - fixed, 0});
@@ -924,6 +930,14 @@ extern "C" int f110_step(f110_handle *h, const double *actions, void *stream)
     if (rc) return rc;
     if (!actions) return fail(F110_E_INVALID, "f110_step: null actions");
     return run_step(h, actions, 0, (hipStream_t)stream);
+}
+
+extern "C" int f110_set_scan_stages(f110_handle *h, const char *spec)
+{
+    if (!h) return fail(F110_E_INVALID, "f110_set_scan_stages: null handle");
+    h->stages = spec ? spec : "";
+    h->epoch++;
+    return F110_OK;
 }
 
 extern "C" int f110_launch_epoch(f110_handle *h, int64_t *epoch)

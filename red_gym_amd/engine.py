@@ -345,6 +345,10 @@ class Engine(object):
         self._keep_wp = waypoints
         return out.view(self.B, self.A, 2) if state is None else out
 
+    def set_scan_stages(self, spec=None):
+        """Wave -> car mapping of the scan launches (f110_set_scan_stages): e.g. '*:-2,6144:0,2048:2'."""
+        _lib.check(self.lib.f110_set_scan_stages(self._h, None if spec is None else spec.encode()))
+
     def launch_epoch(self):
         """Changes whenever a captured hipGraph of step() has gone stale (f110_launch_epoch)."""
         e = C.c_int64(0)

@@ -109,7 +109,7 @@ class F110VecEnv(object):
         self.eng.host_steps_bound = max(self.eng.host_steps_bound, int(self.eng.t['noise_step'].max().item()) + 1)
 
     # ------------------------------------------------------------------ hipGraph replay
-    def capture_step(self, policy=None):
+    def capture_step(self, policy=None, copies=2):
         """Captures one step (optionally preceded by a device-side policy that fills the
         action buffer, e.g. `lambda env, out: env.eng.pure_pursuit(wp, tlad, vgain, out=out)`)
         into a HIP graph.  f110_step neither allocates nor synchronises, so the three or four
@@ -120,17 +120,23 @@ class F110VecEnv(object):
             self._g_actions = torch.zeros((self.num_envs, self.num_agents, 2), dtype=torch.float64, device=self.device)
         self._g_policy = policy
         self.eng._grow_noise_if_needed()
-        side = torch.cuda.Stream(device=self.device)
-        side.wait_stream(torch.cuda.current_stream(self.device))
-        self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.stream(side):
-            with torch.cuda.graph(self._graph, stream=side):
-                if policy is not None:
-                    policy(self, self._g_actions.view(-1, 2))
-                self.eng.step(self._g_actions)
-        torch.cuda.current_stream(self.device).wait_stream(side)
-        # the capture itself did not execute anything; undo its host-side step accounting
-        self.eng.host_steps_bound -= 1
+        # `copies` identical graphs replayed in turn: the HIP runtime does not overlap a graph exec with its own
+        # previous launch, so replaying ONE exec back to back serialises submission with execution; with two the
+        # host submits step k+1 while step k runs (tools/graph_vs_eager.py)
+        self._graphs, self._g_next = [], 0
+        for _ in range(max(1, int(copies))):
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(g, stream=side):
+                    if policy is not None:
+                        policy(self, self._g_actions.view(-1, 2))
+                    self.eng.step(self._g_actions)
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            self.eng.host_steps_bound -= 1  # the capture executed nothing: undo its host-side step accounting
+            self._graphs.append(g)
+        self._g_copies = len(self._graphs)
         # a capture freezes the kernel choice and the by-value arguments (noise table address and length, map
         # template flags, env -> map table): it is valid for this launch epoch only
         self._g_epoch = self.eng.launch_epoch()
@@ -145,8 +151,9 @@ class F110VecEnv(object):
             self._g_actions.copy_(self._as_dev(actions, 2))
         self.eng._grow_noise_if_needed()
         if self.eng.launch_epoch() != self._g_epoch:
-            self.capture_step(self._g_policy)
-        self._graph.replay()
+            self.capture_step(self._g_policy, self._g_copies)
+        self._graphs[self._g_next].replay()
+        self._g_next = (self._g_next + 1) % len(self._graphs)
         self.eng.host_steps_bound += 1
         return self._result()
 

@@ -156,3 +156,32 @@ def test_trajectory_recorder(assets, tmp_path):
     out = np.load(e1.save_recording(str(tmp_path / 'single.npz')))
     assert out['state'].shape == (4, 1, 1, 7) and abs(out['state'][-1, 0, 0, 0] - obs['poses_x'][0]) < 1e-15
     e1.close()
+
+
+def test_lidar_dataset_writer_reference_format(golden, assets, tmp_path):
+    """f4: LidarDatasetWriter writes the reference's dataset format (f1tenth_gym/examples/lidar.py:250-254: key
+    'data', uint8 [N,256,256] of 0/1) and, fed the scans the reference's own main() saw (g12), the reference's own
+    array; record_episodes runs the reference's recording loop on a batch."""
+    import torch
+    from red_gym_amd import F110VecEnv
+    from red_gym_amd.recorder import LidarDatasetWriter
+    g = golden('g12_pointgrid.npz')
+    shape = tuple(g['shape'])
+    want = np.unpackbits(g['data_bits'], axis=-1)[..., :shape[-1]].reshape(shape)
+    w = LidarDatasetWriter('cuda:0', capacity=64)
+    scans = torch.as_tensor(g['scans'], device='cuda')
+    assert w.add(scans[:20]) == 20 and w.add(scans[20:]) == shape[0] - 20
+    path = str(tmp_path / 'lidar_dataset_ep5.npz')
+    assert w.save(path) == shape[0]
+    f = np.load(path, allow_pickle=False)
+    assert f.files == ['data'] and f['data'].dtype == np.uint8 and f['data'].shape == shape
+    assert np.array_equal(f['data'], want)
+    with pytest.raises(IndexError):
+        w.add(torch.zeros((64, 1080), device='cuda'))
+    # the recording loop on a batch: 32 episodes x <= 10 steps, frames only while the episode is alive
+    env = F110VecEnv(32, map=os.path.join(assets, 'example_map'), map_ext='.png', num_agents=1, autoreset=False, fov=4.7)
+    ds = LidarDatasetWriter.record_episodes(env, steps=10, seed=3)
+    d = ds.array()
+    assert d.dtype == np.uint8 and d.shape[1:] == (256, 256) and 32 <= d.shape[0] <= 320 and set(np.unique(d)) <= {0, 1}
+    assert d.reshape(len(d), -1).sum(1).min() > 0
+    env.close()

@@ -472,3 +472,41 @@ def test_check_done_argument_errors():
         check_done(*args, ego_idx=2)
     with pytest.raises(ValueError):
         check_done(*(args[:6] + [z((2, 2), torch.int64), args[7]]))
+
+
+@pytest.mark.parametrize('spec', ['*:0', '*:1', '*:3', '8:0,*:2', '6:2,*:0,10:1', '20:3,*:0,4:2'])
+@pytest.mark.parametrize('A', [1, 2])
+def test_scan_stage_lists_give_identical_results(assets, spec, A):
+    """The wave -> car mapping of a scan launch (one wavefront per car, or 2 / 4 / 8 per car splitting its beam queue,
+    in any sequence of stages) must not change a bit: scans, lookup counts per car, state,
+    collisions, lap flags of 40 autoreset steps `==` the default mapping (itself checked against the oracle above),
+    including cars that start inside a wall (no ray leaves the car), masked resets (scan launches that skip cars)
+    and the function-level scan with poses off the map."""
+    import torch
+    from red_gym_amd import workload
+    B, T = 50, 40
+    poses = workload.spawn_poses(B, A)
+    poses[3, 0, :2] = [0.0, 20.0]       # inside a wall / off the track: d0 <= eps or > max_range paths
+    poses[17, A - 1, :2] = [-78.0, -44.0]
+    poses[18, 0, :2] = [500.0, 500.0]   # off the map: dt[-1,-1] = 51 m > max_range
+    acts = torch.as_tensor(workload.action_pool(8, B, A), device='cuda')
+    e1 = _vec(assets, B, A, autoreset=True, count_lookups=True)
+    e2 = _vec(assets, B, A, autoreset=True, count_lookups=True)
+    e2.eng.set_scan_stages(spec)
+    e1.reset(poses); e2.reset(poses)
+    keys = ('scans_f64', 'scans', 'state', 'lookups', 'collisions', 'in_collision', 'toggles', 'done', 'noise_step')
+    for k in range(T):
+        e1.step(acts[k % 8]); e2.step(acts[k % 8])
+        if k == 20:   # masked reset: only some envs take part in the reset's scan launch
+            m = torch.zeros(B, dtype=torch.uint8, device='cuda'); m[::3] = 1
+            e1.reset(poses, m); e2.reset(poses, m)
+        for key in keys:
+            assert torch.equal(e1.eng.t[key], e2.eng.t[key]), (k, key)
+    assert int(e1.eng.t['done'].sum()) >= 0 and int(e1.eng.t['lookups'].min()) > 0
+    # function-level scan (pose stride 3, no noise), odd pose count
+    rng = np.random.default_rng(5)
+    ps = np.concatenate([workload.spawn_poses(37, 1)[:, 0], rng.uniform(-120, 120, (6, 3))])
+    a64, a32, alk = e1.eng.scan(ps, want_f32=True, want_lookups=True)
+    b64, b32, blk = e2.eng.scan(ps, want_f32=True, want_lookups=True)
+    assert torch.equal(a64, b64) and torch.equal(a32, b32) and torch.equal(alk, blk)
+    e1.close(); e2.close()

@@ -110,3 +110,18 @@ def test_point_grid_oracle_equals_the_reference_dataset(golden):
     assert shape[1:] == (256, 256) and set(np.unique(data)) <= {0, 1} and data.sum() > 0
     for k in range(shape[0]):
         assert np.array_equal(ob.occupancy(g['scans'][k]), data[k]), k
+
+
+def test_reference_dataset_files_have_the_format_the_writer_targets():
+    """The reference ships datasets its recorder wrote (f1tenth_gym/examples/lidar_datasets/*.npz): key 'data',
+    uint8 [N,256,256], values {0, 1} -- the format LidarDatasetWriter.save reproduces (checked on the GPU against
+    g12).  Dev container only: the reference tree does not exist on the GPU box."""
+    import glob
+    files = sorted(glob.glob('/root/reference/f1tenth_gym/examples/lidar_datasets/*.npz'))
+    if not files:
+        pytest.skip('reference tree not present')
+    for f in files[:3]:
+        d = np.load(f, allow_pickle=False)   # plain arrays: nothing is unpickled
+        assert d.files == ['data']
+        a = d['data']
+        assert a.dtype == np.uint8 and a.ndim == 3 and a.shape[1:] == (256, 256) and set(np.unique(a)) <= {0, 1}

@@ -12,12 +12,26 @@ def find(pattern):
     return sorted(glob.glob(os.path.join(out, pattern), recursive=True))
 
 
-print('== kernel stats (rocprofv3 --kernel-trace --stats) ==')
-for f in find('stats/**/*kernel_stats.csv') + find('bitmap_stats/**/*kernel_stats.csv'):
-    for row in csv.DictReader(open(f)):
-        print('%-70s calls %6s  avg_us %10.2f  total_ms %10.3f  pct %6s' % (
-            row['Name'][:70], row['Calls'], float(row['AverageNs']) / 1e3, float(row['TotalDurationNs']) / 1e6,
-            row['Percentage']))
+for label, pat in (('bench.py', 'stats/**/*kernel_stats.csv'), ('tools/bench_bitmap.py', 'bitmap_stats/**/*kernel_stats.csv')):
+    print('== kernel stats of %s (rocprofv3 --kernel-trace --stats) ==' % label)
+    for f in find(pat):
+        for row in csv.DictReader(open(f)):
+            if float(row['Percentage']) < 0.05:
+                continue
+            print('%-70s calls %6s  avg_us %10.2f  total_ms %10.3f  pct %6s' % (
+                row['Name'][:70], row['Calls'], float(row['AverageNs']) / 1e3, float(row['TotalDurationNs']) / 1e6,
+                row['Percentage']))
+    print()
+# the bench's own events bracket the K TIMED launches only; the stats above average every launch of the process
+# (spin-up, reset, warm-up too), so the same K dispatches are averaged from the trace for comparison
+for f in find('stats/**/*kernel_trace.csv'):
+    rows = [r for r in csv.DictReader(open(f)) if 'scan_kernel' in r['Kernel_Name']]
+    rows.sort(key=lambda r: int(r['Start_Timestamp']))
+    d = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3 for r in rows]
+    K = 20
+    if len(d) >= K:
+        print('scan_kernel from the kernel trace: %d dispatches, mean %.2f us; the last %d (the timed region of '
+              '`bench.py --steps %d`): mean %.2f us, min %.2f, max %.2f' % (len(d), sum(d) / len(d), K, K, sum(d[-K:]) / K, min(d[-K:]), max(d[-K:])))
 print()
 print('== bench line under rocprof ==')
 for f in find('bench_under_rocprof.json'):
