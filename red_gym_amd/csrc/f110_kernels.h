@@ -361,23 +361,32 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
         bool active = false;
         int beam = -1;          // beam whose result `total` holds (-1: none)
         double x = px, y = py, c = 0, s = 0, total = 0;
+        double nz = 0, sd = 0;  // noise and side distance of the lane's beam (fetched when the beam is taken)
         for (;;) {
             // ---- refill phase: idle lanes finish their beam and take the next one ----
             const unsigned long long idle = vote(!active);
             const int nidle = __popcll(idle);
             if (!active) {
-                // all independent loads first (one memory round trip): the finished beam's
-                // noise / side distance and the new beam's number
-                const unsigned pb16 = (unsigned)max(beam, 0) * 16u; // 32-bit byte offset: scalar base + VGPR offset
-                const double2 nsv = STEP ? *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(ns) + (size_t)pb16)
-                                         : make_double2(0.0, 0.0);
-                const double nzv = nsv.x, sdv = nsv.y;
+                // all independent loads first (one memory round trip).  The noise / side-distance entry is fetched
+                // for the beam being TAKEN and carried in registers until the beam is finished: idle lanes take
+                // consecutive beams, so this gather touches a few cache lines, where a gather by the FINISHED beams
+                // (scattered over the scan) touched a line per lane -- the L1's tag pipeline is what bounds this kernel
                 const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32),
                                     __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
                 const int k = next + rank;
                 const bool take = k < nbl;
                 const int kk = take ? k : 0;
                 const int b = s_chunk0[(kk >> 6) * wpc + part] + (kk & 63);
+#if defined(F110_NOISE_AT_EMIT) // round-1 variant, kept for A/B runs
+                const unsigned pb16 = (unsigned)max(beam, 0) * 16u; // 32-bit byte offset: scalar base + VGPR offset
+                const double2 nsv = STEP ? *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(ns) + (size_t)pb16)
+                                         : make_double2(0.0, 0.0);
+                const double nzv = nsv.x, sdv = nsv.y;
+#else
+                const double2 nsv = STEP ? *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(ns) + (size_t)((unsigned)b * 16u))
+                                         : make_double2(0.0, 0.0);
+                const double nzv = nz, sdv = sd;
+#endif
                 const int ti = beam_theta_index(T0, t0w, b, a.scan);
                 const double2 cs = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(a.scan.cs) + (size_t)((unsigned)ti * 16u)); // second round trip, overlapped with emit()
                 if (beam >= 0) emit(beam, total, nzv, sdv);
@@ -392,6 +401,10 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
                     y = py + d0 * s;
                     total = d0;
                     beam = b;
+#if !defined(F110_NOISE_AT_EMIT)
+                    nz = nsv.x;
+                    sd = nsv.y;
+#endif
                     active = true;
                 }
             }

@@ -9,6 +9,7 @@ obs has the reference's keys and container types (base_classes.py:587-603,
 f110_env.py:277-278): lists of Python floats, 'scans' a list of float64 arrays.
 """
 import numpy as np
+import torch
 
 try:  # gym is optional: only the base class and registration come from it
     import gym
@@ -58,15 +59,21 @@ class F110Env(_Base):
 
     def _collect(self):
         t = self._vec.eng.t
-        # one device->host hop for the small fields, one for the scans
-        st = t['state'][0].cpu().numpy()
+        A = self.num_agents
+        # two device -> host hops per step: every small field packed into one fp64 row (all of them are exactly
+        # representable: counters, flags, fp64 times), and the scans
+        small = torch.cat([t['state'][0].reshape(-1), t['collisions'][0].to(torch.float64), t['lap_times'][0],
+                           t['lap_counts'][0].to(torch.float64), t['toggles'][0].to(torch.float64),
+                           t['current_time'][0:1], t['done'][0:1].to(torch.float64)]).cpu().numpy()
         scans = t['scans_f64'][0].cpu().numpy()
-        self.collisions = t['collisions'][0].cpu().numpy().astype(np.float64)
-        self.lap_times = t['lap_times'][0].cpu().numpy().copy()
-        self.lap_counts = t['lap_counts'][0].cpu().numpy().astype(np.float64)
-        self.toggle_list = t['toggles'][0].cpu().numpy().astype(np.float64)
-        self.current_time = float(t['current_time'][0].item())
-        done = bool(t['done'][0].item())
+        st = small[:7 * A].reshape(A, 7)
+        o = 7 * A
+        self.collisions = small[o:o + A].copy()
+        self.lap_times = small[o + A:o + 2 * A].copy()
+        self.lap_counts = small[o + 2 * A:o + 3 * A].copy()
+        self.toggle_list = small[o + 3 * A:o + 4 * A].copy()
+        self.current_time = float(small[o + 4 * A])
+        done = bool(small[o + 4 * A + 1])
         obs = {'ego_idx': self.ego_idx,
                'scans': [scans[i].copy() for i in range(self.num_agents)],
                'poses_x': [float(st[i, 0]) for i in range(self.num_agents)],
