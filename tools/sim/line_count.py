@@ -209,3 +209,54 @@ if __name__ == '__main__':
                 l16 += len({f16(r, c)[1] for _, (r, c) in reads})
         n = 12
         print('%-72s gathers/car %6.1f  lanes/gather %4.1f  per-quad lines/car: u16 %6.0f  u8 %6.0f   distinct lines/car %6.0f' % (label, g / n, lk / g, q16 / n, q8 / n, l16 / n))
+
+
+def replay_quads_lane_exit(cells, order, idle_min=40, group=4):
+    """cheap variant: the march loop still leaves when >= idle_min LANES are idle (the kernel's existing scalar test);
+    at the refill every idle lane finishes its beam, but only lanes of fully idle groups take new (adjacent) beams."""
+    ng = 64 // group
+    lane_beam = [-1] * 64
+    lane_pos = [0] * 64
+    nxt, nb = 0, len(order)
+    while True:
+        idle_g = [g for g in range(ng) if all(lane_beam[g * group + j] < 0 for j in range(group))]
+        for g in idle_g:
+            if nxt >= nb:
+                break
+            for j in range(group):
+                if nxt < nb:
+                    b = order[nxt]; nxt += 1
+                    if cells[b]:
+                        lane_beam[g * group + j], lane_pos[g * group + j] = b, 0
+        if all(b < 0 for b in lane_beam):
+            if nxt >= nb:
+                return
+            continue
+        go = 64 - idle_min if nxt < nb else 0
+        while True:
+            reads = []
+            for i in range(64):
+                b = lane_beam[i]
+                if b >= 0:
+                    reads.append((i, cells[b][lane_pos[i]]))
+                    lane_pos[i] += 1
+                    if lane_pos[i] >= len(cells[b]):
+                        lane_beam[i] = -1
+            yield reads
+            if sum(b >= 0 for b in lane_beam) <= go:
+                break
+
+
+if __name__ == '__main__':
+    print()
+    for label, gen in [('lane exit at 40 idle, take by fully idle quads', lambda cells: replay_quads_lane_exit(cells, plain, 40, 4)),
+                       ('lane exit at 32 idle, take by fully idle quads', lambda cells: replay_quads_lane_exit(cells, plain, 32, 4)),
+                       ('lane exit at 24 idle, take by fully idle quads', lambda cells: replay_quads_lane_exit(cells, plain, 24, 4)),
+                       ('lane exit at 32 idle, take by fully idle pairs', lambda cells: replay_quads_lane_exit(cells, plain, 32, 2))]:
+        g = lk = q16 = 0
+        for p in poses[:12]:
+            cells = beam_cells(dt, m, p)
+            for reads in gen(cells):
+                g += 1; lk += len(reads)
+                q16 += quad_cost(reads, f16)
+        print('%-72s gathers/car %6.1f  lanes/gather %4.1f  per-quad lines/car: u16 %6.0f' % (label, g / 12, lk / g, q16 / 12))
