@@ -109,7 +109,7 @@ class F110VecEnv(object):
         self.eng.host_steps_bound = max(self.eng.host_steps_bound, int(self.eng.t['noise_step'].max().item()) + 1)
 
     # ------------------------------------------------------------------ hipGraph replay
-    def capture_step(self, policy=None, copies=2):
+    def capture_step(self, policy=None, copies=1):
         """Captures one step (optionally preceded by a device-side policy that fills the
         action buffer, e.g. `lambda env, out: env.eng.pure_pursuit(wp, tlad, vgain, out=out)`)
         into a HIP graph.  f110_step neither allocates nor synchronises, so the three or four
@@ -120,9 +120,8 @@ class F110VecEnv(object):
             self._g_actions = torch.zeros((self.num_envs, self.num_agents, 2), dtype=torch.float64, device=self.device)
         self._g_policy = policy
         self.eng._grow_noise_if_needed()
-        # `copies` identical graphs replayed in turn: the HIP runtime does not overlap a graph exec with its own
-        # previous launch, so replaying ONE exec back to back serialises submission with execution; with two the
-        # host submits step k+1 while step k runs (tools/graph_vs_eager.py)
+        # `copies` > 1 captures that many identical graphs, replayed in turn (an experiment: two alternating execs
+        # replay no faster than one, profiles/r02_graph_vs_eager.txt)
         self._graphs, self._g_next = [], 0
         for _ in range(max(1, int(copies))):
             side = torch.cuda.Stream(device=self.device)

@@ -20,7 +20,7 @@ for B in sizes:
         for k in range(N): env.step(acts[k % 8])
         torch.cuda.synchronize(); res['eager'] = (time.perf_counter() - t0) / N
     if 'graph_copy' in modes or 'graph_nocopy' in modes:
-        buf = env.capture_step()
+        buf = env.capture_step(copies=2)
         for k in range(10): env.step_graph(acts[k % 8])
     if 'graph_copy' in modes:
         torch.cuda.synchronize(); t0 = time.perf_counter()
