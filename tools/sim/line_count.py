@@ -142,12 +142,6 @@ def replay_quads(cells, order, idle_quads_min=10, group=4):
                 break
 
 
-def replay_lanes_tagged(cells, order, idle_min=40):
-    lane_of = {}
-    for reads in replay_with_lanes(cells, order, idle_min):
-        yield reads
-
-
 def replay_with_lanes(cells, order, idle_min=40):
     lane_beam = [-1] * 64
     lane_pos = [0] * 64
