@@ -254,3 +254,46 @@ if __name__ == '__main__':
                 g += 1; lk += len(reads)
                 q16 += quad_cost(reads, f16)
         print('%-72s gathers/car %6.1f  lanes/gather %4.1f  per-quad lines/car: u16 %6.0f' % (label, g / 12, lk / g, q16 / 12))
+
+
+if __name__ == '__main__':
+    # The counter calibrated (rocprofv3 on tools/ubench/gather_cost2): TCP_TOTAL_CACHE_ACCESSES of a 64-lane gather =
+    # sum over its four 16-LANE groups of the distinct 128-B lines the group touches.  Same policies, that metric:
+    print('\n16-lane-group metric (what TCP_TOTAL_CACHE_ACCESSES counts):')
+    for label, gen in [('lane-granular taking, exit at 40 idle (shipped)', lambda cells: replay_with_lanes(cells, so)),
+                       ('quad taking, exit at 32 idle lanes (measured: +8 % gathers, +3 % accesses)', lambda cells: replay_quads_lane_exit(cells, plain, 32, 4)),
+                       ('8-lane taking, exit at 32 idle lanes', lambda cells: replay_quads_lane_exit(cells, plain, 32, 8)),
+                       ('16-lane taking, exit at 32 idle lanes', lambda cells: replay_quads_lane_exit(cells, plain, 32, 16)),
+                       ('16-lane taking, exit at 16 idle lanes', lambda cells: replay_quads_lane_exit(cells, plain, 16, 16)),
+                       ('16-lane taking, refill when 1 group idle', lambda cells: replay_quads(cells, plain, 1, 16)),
+                       ('16-lane taking, refill when 2 groups idle', lambda cells: replay_quads(cells, plain, 2, 16))]:
+        g = lk = acc = 0
+        for p in poses[:12]:
+            cells = beam_cells(dt, m, p)
+            for reads in gen(cells):
+                g += 1; lk += len(reads)
+                acc += quad_cost(reads, f16, 16)
+        print('%-80s gathers/car %6.1f  lanes/gather %4.1f  L1 accesses/car %6.0f  per gather %5.1f' % (label, g / 12, lk / g, acc / 12, acc / g))
+
+
+if __name__ == '__main__':
+    print('\ncell layouts under the calibrated metric, shipped taking policy; footprint = distinct lines a car touches in one scan:')
+    lay = {'u16, 8-col strips: 128 B = 8x8 cells (shipped)': lambda r, c: (c >> 3, r >> 3),
+           'u8, 8-col strips: 128 B = 16 rows x 8 cols': lambda r, c: (c >> 3, r >> 4),
+           'u8, 16-col strips: 128 B = 8 rows x 16 cols': lambda r, c: (c >> 4, r >> 3),
+           'u8, 128 B = 12x10-ish (11 x 11 cells, 7 B wasted)': lambda r, c: (c // 11, r // 11),
+           '4-bit codes: 128 B = 16 x 16 cells': lambda r, c: (c >> 4, r >> 4)}
+    for name, f in lay.items():
+        g = acc = foot = 0
+        for p in poses[:12]:
+            cells = beam_cells(dt, m, p)
+            seen = set()
+            for reads in replay_with_lanes(cells, so):
+                g += 1
+                per = {}
+                for lane, (r, c) in reads:
+                    per.setdefault(lane >> 4, set()).add(f(r, c))
+                    seen.add(f(r, c))
+                acc += sum(len(v) for v in per.values())
+            foot += len(seen)
+        print('%-52s L1 accesses/car %6.0f (per gather %5.2f)   lines touched per scan %5.0f' % (name, acc / 12, acc / g, foot / 12))
