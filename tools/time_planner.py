@@ -1,0 +1,20 @@
+"""Times f110_pure_pursuit alone on the benchmark's spawn poses: python tools/time_planner.py [envs]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from red_gym_amd import F110VecEnv, workload
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+env = F110VecEnv(B, map=workload.EXAMPLE_MAP, num_agents=1, autoreset=True)
+env.reset(torch.as_tensor(workload.spawn_poses(B, 1), device=env.device))
+rl = workload.load_waypoints(workload.RACELINE)
+wp = torch.as_tensor(np.ascontiguousarray(rl[:, [1, 2, 5]]), device=env.device)
+for _ in range(20):
+    env.step(env.pure_pursuit(wp, 0.82461887897713965, 1.375))
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+torch.cuda.synchronize(); e0.record()
+for _ in range(100):
+    a = env.pure_pursuit(wp, 0.82461887897713965, 1.375)
+e1.record(); torch.cuda.synchronize()
+print('%s: pure_pursuit_kernel %d cars, %d waypoints: %.1f us per call' % (os.path.basename(os.environ.get('F110_LIB', 'default')), B, wp.shape[0], e0.elapsed_time(e1) * 10))
+env.close()
