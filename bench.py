@@ -162,18 +162,29 @@ def self_launch(n, argv):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
     rc = 0
     live = set(range(n))
-    while live:
-        for r in sorted(live):
-            code = procs[r].poll()
-            if code is None:
-                continue
-            live.discard(r)
-            if code != 0 and rc == 0:
-                rc = code
-                sys.stderr.write('bench.py: rank %d exited with code %d; stopping the other ranks\n' % (r, code))
-                for q in live:
-                    procs[q].terminate()
-        time.sleep(0.05)
+    try:
+        while live:
+            for r in sorted(live):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                live.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code
+                    sys.stderr.write('bench.py: rank %d exited with code %d; stopping the other ranks\n' % (r, code))
+                    for q in live:
+                        procs[q].terminate()
+            time.sleep(0.05)
+    finally:
+        # the launcher itself is being stopped (timeout, Ctrl-C): do not leave ranks behind
+        for r in live:
+            if procs[r].poll() is None:
+                procs[r].terminate()
+        for r in live:
+            try:
+                procs[r].wait(timeout=10)
+            except Exception:
+                procs[r].kill()
     return rc
 
 
