@@ -993,15 +993,15 @@ extern "C" int f110_pure_pursuit(f110_handle *h, const double *waypoints, int32_
     if (n < 0) return fail(F110_E_INVALID, "f110_pure_pursuit: bad arguments");
     if (n == 0) return F110_OK;
     if (!waypoints || !state || !actions) return fail(F110_E_INVALID, "f110_pure_pursuit: null pointer");
-    if (M < 2 || (size_t)M * 3 * sizeof(double) > 150 * 1024)
+    if (M < 2 || pure_pursuit_lds_bytes(M) > 156 * 1024)
         return fail(F110_E_INVALID, "f110_pure_pursuit: M=%d waypoints (2..6400: the raceline is staged in LDS)", M);
     PlanArgs a;
     a.waypoints = waypoints; a.M = M; a.lookahead = lookahead; a.vgain = vgain; a.wheelbase = wheelbase;
     a.max_reacquire = max_reacquire; a.state = state; a.n = n; a.actions = actions;
-    const size_t smem = (size_t)M * 3 * sizeof(double);
+    const size_t smem = pure_pursuit_lds_bytes(M);
     if (smem > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)pure_pursuit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    hipLaunchKernelGGL(pure_pursuit_kernel, dim3((n + 255) / 256), dim3(256), smem, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(pure_pursuit_kernel, dim3((n + PP_WAVES - 1) / PP_WAVES), dim3(PP_WAVES * 64), smem, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return F110_OK;
 }

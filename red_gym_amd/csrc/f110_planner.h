@@ -1,5 +1,5 @@
 // f110_planner.h -- batched pure-pursuit planner: the caller on the other
-// side of F110Env.step, reference examples/waypoint_follow.py:15-217, one lane per car.
+// side of F110Env.step, reference examples/waypoint_follow.py:15-217, one wavefront per car.
 // fp64, plain mul/add in the reference's order (its np.dot calls are BLAS-rounded, see DESIGN.md
 // section 2); checked against oracle/planner.py in the tests.
 #pragma once
@@ -34,56 +34,163 @@ __device__ inline bool seg_circle(double sx, double sy, double ex, double ey, do
     return true;
 }
 
-__global__ __launch_bounds__(256) void pure_pursuit_kernel(PlanArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) double s_wp[]; // [M,3]
-    for (int i = threadIdx.x; i < a.M * 3; i += blockDim.x) s_wp[i] = a.waypoints[i];
-    __syncthreads();
-    const int car = blockIdx.x * blockDim.x + threadIdx.x;
-    if (car >= a.n) return;
-    const int M = a.M;
-    const double px = a.state[(size_t)car * 7], py = a.state[(size_t)car * 7 + 1], theta = a.state[(size_t)car * 7 + 4];
+// One WAVEFRONT per car (round 2; round 1 ran one lane per car, every lane walking all M - 1 segments: 128 us for
+// 65 536 cars on the 783-point example raceline).  The 64 lanes evaluate 64 consecutive segments at once, and whole
+// 64-segment blocks are skipped when their bounding box is farther from the car than a distance already found --
+// which is only possible because a wave serves ONE car (lanes with different cars would need different blocks).
+// The results are the reference's: first arg-min of the sqrt'd distances (ties go to the lower index: blocks are
+// visited in index order and replace on strict `<`; a skipped block lies strictly farther than the minimum), and the
+// first segment in the reference's search order whose circle intersection qualifies (a ballot's lowest set bit).
+constexpr int PP_WAVES = 16; // cars per workgroup (they share the LDS copy of the raceline)
 
-    // nearest_point_on_trajectory (:16-47): first arg-min over the M-1 segments
-    double best = __builtin_inf(), best_t = 0;
-    int best_i = 0;
-    for (int i = 0; i < M - 1; i++) {
+// wave-wide min / max of a double with DPP moves (no LDS round trips): xor-1, xor-2 inside quads, mirror inside half rows
+// and rows leave every lane with its 16-lane row's result; the four rows are combined through readlane.
+template <int CTRL>
+__device__ inline double dpp_mov_f64(double v)
+{
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)u, (int)(unsigned)u, CTRL, 0xf, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)(u >> 32), (int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, false);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+__device__ inline double readlane_f64(double v, int l)
+{
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), l);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+template <bool MAX>
+__device__ inline double wave_reduce_f64(double v)
+{
+    auto op = [](double a, double b) { return MAX ? fmax(a, b) : fmin(a, b); };
+    v = op(v, dpp_mov_f64<0xB1>(v));  // quad_perm [1,0,3,2]
+    v = op(v, dpp_mov_f64<0x4E>(v));  // quad_perm [2,3,0,1]
+    v = op(v, dpp_mov_f64<0x141>(v)); // row_half_mirror
+    v = op(v, dpp_mov_f64<0x140>(v)); // row_mirror
+    return op(op(readlane_f64(v, 0), readlane_f64(v, 16)), op(readlane_f64(v, 32), readlane_f64(v, 48)));
+}
+
+__device__ inline double wave_min_f64(double v) { return wave_reduce_f64<false>(v); }
+__device__ inline double wave_max_f64(double v) { return wave_reduce_f64<true>(v); }
+
+__host__ __device__ inline size_t pure_pursuit_lds_bytes(int M)
+{
+    const int nblk = (M - 1 + 63) / 64;
+    return ((size_t)M * 3 + (size_t)nblk * 4) * sizeof(double);
+}
+
+__global__ __launch_bounds__(PP_WAVES * 64) void pure_pursuit_kernel(PlanArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double s_wp[]; // [M,3] waypoints, then [nblk,4] block boxes
+    const int M = a.M, nseg = M - 1, nblk = (nseg + 63) >> 6;
+    double *s_box = s_wp + (size_t)M * 3; // xmin, xmax, ymin, ymax of the points of segments 64b .. 64b+63
+    for (int i = threadIdx.x; i < M * 3; i += blockDim.x) s_wp[i] = a.waypoints[i];
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    for (int b = wave; b < nblk; b += PP_WAVES) {
+        const int i = 64 * b + lane;
+        const bool ok = i < nseg;
+        const double x0 = ok ? s_wp[3 * i] : 0, y0 = ok ? s_wp[3 * i + 1] : 0, x1 = ok ? s_wp[3 * i + 3] : 0, y1 = ok ? s_wp[3 * i + 4] : 0;
+        const double inf = __builtin_inf();
+        const double xl = wave_min_f64(ok ? fmin(x0, x1) : inf), xh = wave_max_f64(ok ? fmax(x0, x1) : -inf);
+        const double yl = wave_min_f64(ok ? fmin(y0, y1) : inf), yh = wave_max_f64(ok ? fmax(y0, y1) : -inf);
+        if (lane == 0) { s_box[4 * b] = xl; s_box[4 * b + 1] = xh; s_box[4 * b + 2] = yl; s_box[4 * b + 3] = yh; }
+    }
+    __syncthreads();
+    __shared__ double s_res[PP_WAVES][4]; // per car of the block: target x, y, speed, 1.0 if there is a target
+    const int car = blockIdx.x * PP_WAVES + wave;
+    const int car_c = min(car, a.n - 1);    // (waves past the last car redo the last one: they must reach the barrier below)
+    const double px = a.state[(size_t)car_c * 7], py = a.state[(size_t)car_c * 7 + 1];
+
+    // distance of this lane's segment of block b (inf past the last segment) and its clipped parameter
+    auto seg_dist = [&](int b, double &t) {
+        const int i = 64 * b + lane;
+        t = 0.0;
+        if (i >= nseg) return __builtin_inf();
         const double x0 = s_wp[3 * i], y0 = s_wp[3 * i + 1];
         const double dx = s_wp[3 * i + 3] - x0, dy = s_wp[3 * i + 4] - y0;
         const double l2 = dx * dx + dy * dy;
-        double t = ((px - x0) * dx + (py - y0) * dy) / l2;
+        t = ((px - x0) * dx + (py - y0) * dy) / l2;
         t = t < 0.0 ? 0.0 : t;
         t = t > 1.0 ? 1.0 : t;
         const double qx = px - (x0 + t * dx), qy = py - (y0 + t * dy);
-        const double dist = sqrt(qx * qx + qy * qy);
-        if (dist < best) { best = dist; best_t = t; best_i = i; }
+        return sqrt(qx * qx + qy * qy);
+    };
+    // lower bound of the distance from the car to anything in block b: its distance to the block's box
+    auto box_dist = [&](int b) {
+        const double ex = fmax(fmax(s_box[4 * b] - px, px - s_box[4 * b + 1]), 0.0);
+        const double ey = fmax(fmax(s_box[4 * b + 2] - py, py - s_box[4 * b + 3]), 0.0);
+        return sqrt(ex * ex + ey * ey);
+    };
+
+    // nearest_point_on_trajectory (:16-47).  Lane j holds the lower bound of block j (+64: a second word for long
+    // racelines); an upper bound comes from the nearest segment of the block whose box is closest; then only the blocks
+    // whose box is within that bound are evaluated, in index order.
+    double lb[2];
+    double lb_best = __builtin_inf();
+    int b_star = 0;
+    for (int w = 0; w < 2; w++) {
+        const int b = 64 * w + lane;
+        lb[w] = b < nblk ? box_dist(b) : __builtin_inf();
+        if (64 * w < nblk) {
+            const double m = wave_min_f64(lb[w]);
+            if (m < lb_best) { lb_best = m; b_star = 64 * w + (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(lb[w] == m)); }
+        }
+    }
+    double t_star;
+    const double d_star = seg_dist(b_star, t_star);
+    const double ub = wave_min_f64(d_star) + 1e-9; // nothing farther than this can be (or tie) the minimum
+    double best = __builtin_inf(), best_t = 0;
+    int best_i = 0;
+    for (int w = 0; w < 2 && 64 * w < nblk; w++) {
+        unsigned long long todo = __builtin_amdgcn_ballot_w64(!(lb[w] > ub)); // (a NaN pose keeps every block)
+        if (64 * w + 64 > nblk) todo &= (~0ull) >> (64 * w + 64 - nblk);
+        while (todo) {
+            const int b = 64 * w + (int)__builtin_ctzll(todo);
+            todo &= todo - 1;
+            double t = t_star;
+            const double d = b == b_star ? d_star : seg_dist(b, t); // (wave-uniform choice)
+            const double m = wave_min_f64(d);
+            if (m < best) { // strict: an equal distance in an earlier block keeps the lower index (np.argmin)
+                const int l = (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(d == m)); // first lane = lowest segment index
+                best = m; best_i = 64 * b + l; best_t = readlane_f64(t, l);
+            }
+        }
     }
 
-    double steer = 0.0, speed = 4.0; // plan(): lookahead_point is None -> (4.0, 0.0)
     bool have = false;
     double lx = 0, ly = 0, lv = 0;
     if (best < a.lookahead) {
-        // first_point_on_trajectory_intersecting_circle(position, lookahead, wpts, i + t, wrap=True)
+        // first_point_on_trajectory_intersecting_circle(position, lookahead, wpts, i + t, wrap=True) (:49-129)
         const double targ = (double)best_i + best_t;
         const int start_i = (int)targ;
         const double start_t = fmod(targ, 1.0);
         int i2 = 0;
         bool found = false;
-        for (int i = start_i; i < M - 1 && !found; i++) {
+        for (int base = start_i; base < M - 1 && !found; base += 64) {
+            const int i = base + lane;
+            bool hit = false;
             double t1, t2;
-            if (!seg_circle(s_wp[3 * i], s_wp[3 * i + 1], s_wp[3 * i + 3], s_wp[3 * i + 4], px, py, a.lookahead, t1, t2)) continue;
-            if (i == start_i) {
-                if (t1 >= 0.0 && t1 <= 1.0 && t1 >= start_t) { found = true; i2 = i; }
-                else if (t2 >= 0.0 && t2 <= 1.0 && t2 >= start_t) { found = true; i2 = i; }
-            } else if (t1 >= 0.0 && t1 <= 1.0) { found = true; i2 = i; }
-            else if (t2 >= 0.0 && t2 <= 1.0) { found = true; i2 = i; }
+            if (i < M - 1 && seg_circle(s_wp[3 * i], s_wp[3 * i + 1], s_wp[3 * i + 3], s_wp[3 * i + 4], px, py, a.lookahead, t1, t2)) {
+                const bool h1 = t1 >= 0.0 && t1 <= 1.0, h2 = t2 >= 0.0 && t2 <= 1.0;
+                hit = i == start_i ? ((h1 && t1 >= start_t) || (h2 && t2 >= start_t)) : (h1 || h2);
+            }
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+            if (m) { found = true; i2 = base + (int)__builtin_ctzll(m); }
         }
-        for (int i = -1; i < start_i && !found; i++) {
-            const int i0 = i < 0 ? i + M : i, i1 = (i + 1) % M; // Python's % on a negative index
+        for (int base = -1; base < start_i && !found; base += 64) {
+            const int i = base + lane;
+            bool hit = false;
             double t1, t2;
-            if (!seg_circle(s_wp[3 * i0], s_wp[3 * i0 + 1], s_wp[3 * i1], s_wp[3 * i1 + 1], px, py, a.lookahead, t1, t2)) continue;
-            if (t1 >= 0.0 && t1 <= 1.0) { found = true; i2 = i; }
-            else if (t2 >= 0.0 && t2 <= 1.0) { found = true; i2 = i; }
+            if (i < start_i) {
+                const int i0 = i < 0 ? i + M : i, i1 = (i + 1) % M; // Python's % on a negative index
+                if (seg_circle(s_wp[3 * i0], s_wp[3 * i0 + 1], s_wp[3 * i1], s_wp[3 * i1 + 1], px, py, a.lookahead, t1, t2))
+                    hit = (t1 >= 0.0 && t1 <= 1.0) || (t2 >= 0.0 && t2 <= 1.0);
+            }
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+            if (m) { found = true; i2 = base + (int)__builtin_ctzll(m); }
         }
         if (found) {
             const int j = i2 < 0 ? i2 + M : i2; // wpts[i2, :] with Python negative indexing
@@ -92,19 +199,29 @@ __global__ __launch_bounds__(256) void pure_pursuit_kernel(PlanArgs a)
     } else if (best < a.max_reacquire) {
         have = true; lx = s_wp[3 * best_i]; ly = s_wp[3 * best_i + 1]; lv = s_wp[3 * best_i + 2];
     }
-    if (have) {
-        // get_actuation (:131-144)
-        const double wy = sin(-theta) * (lx - px) + cos(-theta) * (ly - py);
-        speed = lv;
-        if (fabs(wy) < 1e-6) steer = 0.;
-        else {
-            const double radius = 1 / (2.0 * wy / (a.lookahead * a.lookahead));
-            steer = atan(a.wheelbase / radius);
+    if (lane == 0) { s_res[wave][0] = lx; s_res[wave][1] = ly; s_res[wave][2] = lv; s_res[wave][3] = have ? 1.0 : 0.0; }
+    __syncthreads();
+    // get_actuation (:131-144) for the block's cars, one LANE per car (the trigonometry would otherwise be issued
+    // wave-wide for a single car)
+    if (wave == 0 && lane < PP_WAVES) {
+        const int c = blockIdx.x * PP_WAVES + lane;
+        if (c < a.n) {
+            double steer = 0.0, speed = 4.0; // plan(): lookahead_point is None -> (4.0, 0.0)
+            if (s_res[lane][3] != 0.0) {
+                const double cx = a.state[(size_t)c * 7], cy = a.state[(size_t)c * 7 + 1], theta = a.state[(size_t)c * 7 + 4];
+                const double wy = sin(-theta) * (s_res[lane][0] - cx) + cos(-theta) * (s_res[lane][1] - cy);
+                speed = s_res[lane][2];
+                if (fabs(wy) < 1e-6) steer = 0.;
+                else {
+                    const double radius = 1 / (2.0 * wy / (a.lookahead * a.lookahead));
+                    steer = atan(a.wheelbase / radius);
+                }
+                speed = a.vgain * speed;
+            }
+            a.actions[(size_t)c * 2] = steer;
+            a.actions[(size_t)c * 2 + 1] = speed;
         }
-        speed = a.vgain * speed;
     }
-    a.actions[(size_t)car * 2] = steer;
-    a.actions[(size_t)car * 2 + 1] = speed;
 }
 
 } // namespace f110
