@@ -185,3 +185,45 @@ def test_lidar_dataset_writer_reference_format(golden, assets, tmp_path):
     assert d.dtype == np.uint8 and d.shape[1:] == (256, 256) and 32 <= d.shape[0] <= 320 and set(np.unique(d)) <= {0, 1}
     assert d.reshape(len(d), -1).sum(1).min() > 0
     env.close()
+
+
+@pytest.mark.parametrize('M', [2, 3, 64, 65, 66, 130, 783, 4097, 5000, 6400])
+def test_hip_pure_pursuit_raceline_lengths(M):
+    """The planner kernel works through the raceline in 64-segment blocks (one wavefront per car, blocks skipped by
+    their bounding box, a second mask word beyond 64 blocks): racelines of 2 ... 6400 points -- block boundaries, the
+    >64-block path, the >64 KiB LDS path -- against the NumPy checker on poses on, near, off and far from the line."""
+    import torch
+    from argparse import Namespace
+    from oracle.planner import PurePursuitPlanner, Raceline
+    from red_gym_amd.engine import _lib, _ptr
+    import ctypes as C
+    rng = np.random.default_rng(M)
+    th = np.linspace(0, 2 * np.pi, M, endpoint=False) if M > 3 else np.linspace(0, 1.0, M)
+    R = 5.0 + 0.004 * M
+    xy = np.stack([R * np.cos(th) * (1 + 0.2 * np.sin(3 * th)), 0.7 * R * np.sin(th)], axis=1)
+    v = rng.uniform(2, 8, M)
+    pl = PurePursuitPlanner.__new__(PurePursuitPlanner)
+    pl.wheelbase, pl.max_reacquire, pl.line, pl.speeds = 0.33, 20., Raceline(xy), v
+    n = 96
+    k = rng.integers(0, M, n)
+    poses = np.zeros((n, 7))
+    poses[:, 0] = xy[k, 0] + rng.normal(0, 0.3, n)
+    poses[:, 1] = xy[k, 1] + rng.normal(0, 0.3, n)
+    poses[:16, :2] += rng.normal(0, 3.0, (16, 2))       # beyond the lookahead: re-acquire branch
+    poses[16:20, :2] += 500.0                           # beyond max_reacquire
+    poses[20:24, :2] = xy[[0, -1, M // 2, max(M - 2, 0)]]   # exactly on waypoints (first, last: the wrap search)
+    poses[:, 4] = rng.uniform(-3, 3, n)
+    lookahead = 0.9
+    dev = torch.device('cuda', 0)
+    wp = torch.as_tensor(np.column_stack([xy, v]), device=dev).contiguous()
+    st = torch.as_tensor(poses, device=dev)
+    out = torch.empty((n, 2), dtype=torch.float64, device=dev)
+    lib = _lib.load()
+    _lib.check(lib.f110_pure_pursuit(None, _ptr(wp), M, lookahead, 1.2, 0.33, 20.0, _ptr(st), n, _ptr(out),
+                                     C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    got = out.cpu().numpy()
+    for i in range(n):
+        sp, stg = pl.plan(poses[i, 0], poses[i, 1], poses[i, 4], lookahead, 1.2)
+        assert abs(got[i, 0] - stg) < 1e-12 and abs(got[i, 1] - sp) < 1e-12, (M, i, got[i], (stg, sp))
+    with pytest.raises(ValueError):
+        _lib.check(lib.f110_pure_pursuit(None, _ptr(wp), 1, lookahead, 1.2, 0.33, 20.0, _ptr(st), n, _ptr(out), None))
