@@ -184,8 +184,21 @@ int f110_step(f110_handle *h, const double *actions_dev, void *stream);
 /* Tuning / test hook: how a scan launch maps wavefronts to cars, as "cars:lg,cars:lg,..." in launch order with one
  * "*" for the remaining cars: a car of a stage gets 2^lg wavefronts (lg = 0..3; several short-lived waves per car pay
  * for small batches and at the end of a launch).  NULL or "" restores the built-in choice (or the F110_STAGES
- * environment variable).  Results do not depend on it. */
+ * environment variable).  A malformed list (syntax, lg > 3, two "*", more than 6 stages, more cars than the handle
+ * has) is refused with F110_E_INVALID and changes nothing.  Results do not depend on it. */
 int f110_set_scan_stages(f110_handle *h, const char *spec);
+
+/* Which kernels a step enqueues.  F110_PATH_CLASSIC: dynamics_kernel -> scan_kernel (a wavefront per car, or a fixed
+ * slice of its beams per wavefront) -> [opponent kernels] -> env_kernel.  F110_PATH_GROUP: one WORKGROUP of
+ * `waves_per_car` wavefronts (1..8; 0 = built-in choice) per car, whose waves draw beams from one queue; with
+ * num_agents == 1 the whole step -- RaceCar.update_pose in front, the bookkeeping of F110Env.step / _check_done behind
+ * (f110_env.py:261-302, base_classes.py:254-407) -- is that ONE launch.  F110_PATH_AUTO (default): car groups for small
+ * launches (<= 8 192 cars), where the chip is underfilled and launch overheads count; classic above.  Results do not
+ * depend on the path (same device functions; a beam's value does not depend on the lane that marched it). */
+#define F110_PATH_AUTO 0
+#define F110_PATH_CLASSIC 1
+#define F110_PATH_GROUP 2
+int f110_set_step_path(f110_handle *h, int32_t path, int32_t waves_per_car);
 
 /* hipGraph support.  f110_step only enqueues kernels (no allocation, no synchronisation), so it can be captured
  * into a HIP graph and replayed.  A capture freezes the kernel selection and the by-value launch arguments; the

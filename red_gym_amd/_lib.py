@@ -66,6 +66,7 @@ SYMBOLS = {
     'f110_reset': [_VP, _VP, _VP, _VP],
     'f110_step': [_VP, _VP, _VP],
     'f110_set_scan_stages': [_VP, C.c_char_p],
+    'f110_set_step_path': [_VP, _I32, _I32],
     'f110_launch_epoch': [_VP, C.POINTER(C.c_int64)],
     'f110_pure_pursuit': [_VP, _VP, _I32, _D, _D, _D, _D, _VP, _I32, _VP, _VP],
     'f110_profile_begin': [_VP, _I32],

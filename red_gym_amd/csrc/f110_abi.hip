@@ -52,6 +52,8 @@ struct f110_handle {
     // (a table re-allocated, another scan instantiation selected, buffers re-bound): f110_launch_epoch.
     int64_t epoch = 0;
     std::string stages;               // f110_set_scan_stages override ("" = F110_STAGES or the built-in choice)
+    int step_path = F110_PATH_AUTO;   // f110_set_step_path
+    int group_waves = 0;              // wavefronts per car of the car-group path (0 = built-in choice)
     f110_buffers bufs;
     // device tables owned by the handle
     double *d_scan_angles = nullptr, *d_beam_cosines = nullptr, *d_side = nullptr;
@@ -783,6 +785,39 @@ static int waves_per_car(int n_cars, int num_beams)
     return wpc;
 }
 
+struct StageSpec { int cars, lg; }; // cars < 0: "*", the remaining cars
+
+// "cars:log2waves,..." with at most one "*": strict syntax (f110_set_scan_stages refuses what this refuses)
+static bool parse_stage_spec(const char *p, std::vector<StageSpec> &spec, const char **why)
+{
+    spec.clear();
+    int stars = 0;
+    if (!p || !*p) { *why = "empty"; return false; }
+    for (;;) {
+        int cars = -1, lg = 0;
+        if (*p == '*') { p++; stars++; }
+        else if (*p >= '0' && *p <= '9') {
+            long v = strtol(p, (char **)&p, 10);
+            if (v > 0x3fffffff) { *why = "car count too large"; return false; }
+            cars = (int)v;
+        } else { *why = "expected a car count or *"; return false; }
+        if (*p == ':') {
+            p++;
+            if (!(*p >= '0' && *p <= '9')) { *why = "expected log2(waves per car) after ':'"; return false; }
+            long v = strtol(p, (char **)&p, 10);
+            if (v > SCAN_MAX_LOG2W) { *why = "log2(waves per car) above 3"; return false; }
+            lg = (int)v;
+        }
+        spec.push_back({cars, lg});
+        if (*p == ',') { p++; continue; }
+        if (*p) { *why = "unexpected character"; return false; }
+        break;
+    }
+    if (stars > 1) { *why = "more than one *"; return false; }
+    if (spec.size() > 6) { *why = "more than 6 stages"; return false; }
+    return true;
+}
+
 static int launch_scan(f110_handle *h, const ScanArgs &a_in, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr)
 {
     ScanArgs a = a_in;
@@ -803,27 +838,20 @@ static int launch_scan(f110_handle *h, const ScanArgs &a_in, hipStream_t st, hip
     const char *stages_env = h->stages.empty() ? stages_env0 : h->stages.c_str();
     const int nch = (a.scan.nb + 63) / 64;
     int lg_all = a.wpc >= 8 ? 3 : a.wpc >= 4 ? 2 : a.wpc >= 2 ? 1 : 0;
-    struct St { int cars, lg; };
+    typedef StageSpec St;
     std::vector<St> stv;
     if (h->stages.empty() && (lg_all > 0 || nch < 8)) stv.push_back({a.n_cars, lg_all});
     else {
         std::vector<St> spec;
-        if (stages_env) {
-            const char *p = stages_env;
-            while (*p) {
-                int cars = -1, lg = 0;
-                if (*p == '*') { p++; } else cars = (int)strtol(p, (char **)&p, 10);
-                if (*p == ':') lg = (int)strtol(p + 1, (char **)&p, 10);
-                spec.push_back({cars, std::max(0, std::min(3, lg))});
-                if (*p == ',') p++; else break;
-            }
-        } else {
+        const char *why = nullptr;
+        if (!stages_env || !parse_stage_spec(stages_env, spec, &why)) { // (a malformed F110_STAGES: the built-in choice)
             const int tail = std::min(2048, a.n_cars / 2);
             spec = {{-1, 0}, {tail, 2}};
         }
         int fixed = 0;
         for (auto &x : spec) if (x.cars >= 0) { x.cars -= x.cars % SCAN_WAVES; fixed += x.cars; }
-        if (fixed > a.n_cars || spec.size() > 6) { spec = {{-1, 0}}; fixed = 0; }
+        // a list written for the step's car count may not fit a function-level scan of fewer poses: whole cars then
+        if (fixed > a.n_cars) { spec = {{-1, 0}}; fixed = 0; }
         bool star = false;
         for (auto &x : spec) if (x.cars < 0 && !star) { x.cars = a.n_cars - fixed; star = true; }
         if (!star) spec.push_back({a.n_cars - fixed, 0});
@@ -834,10 +862,70 @@ static int launch_scan(f110_handle *h, const ScanArgs &a_in, hipStream_t st, hip
             if (w % SCAN_WAVES) { stv.assign(1, {a.n_cars, 0}); break; }
         }
     }
-    if (stv.size() > 8) stv.assign(1, {a.n_cars, 0});
+    if (stv.size() > (size_t)SCAN_MAX_STAGES) stv.assign(1, {a.n_cars, 0});
     a.n_stages = (int)stv.size();
+    // what the kernel assumes about the stage list, checked here where a mistake costs an error code instead of a
+    // wave -> car mapping that runs off the argument block
+    if (a.n_stages < 1 || a.n_stages > SCAN_MAX_STAGES) return fail(F110_E_INVALID, "scan launch: %d stages (1..%d)", a.n_stages, SCAN_MAX_STAGES);
+    {
+        long long cars = 0;
+        for (const St &x : stv) {
+            if (x.cars < 0 || x.lg < 0 || x.lg > SCAN_MAX_LOG2W) return fail(F110_E_INVALID, "scan launch: stage (%d cars, 2^%d waves per car) out of range", x.cars, x.lg);
+            cars += x.cars;
+        }
+        if (cars != a.n_cars) return fail(F110_E_INVALID, "scan launch: the stages cover %lld cars, the launch has %d", cars, a.n_cars);
+    }
     for (int i = 0; i < 8; i++) { a.stage_cars[i] = i < a.n_stages ? stv[i].cars : 0; a.stage_log2w[i] = i < a.n_stages ? stv[i].lg : 0; }
     return a.state ? launch_scan_t<true>(h, a, st, ev0, ev1) : launch_scan_t<false>(h, a, st, ev0, ev1);
+}
+
+// ---- car-group path (car_group_kernel): one workgroup of `waves` wavefronts per car
+// Which launches take it.  Measured on MI355X (profiles/r03_group_sweep.txt); F110_GROUP="waves[:max_cars]" overrides the
+// built-in choice for sweeps, f110_set_step_path for a handle.  Returns the wavefronts per car, 0 = classic path.
+static int group_waves_for(const f110_handle *h, int n_cars)
+{
+    if (h->step_path == F110_PATH_CLASSIC) return 0;
+    static const char *env = getenv("F110_GROUP");
+    int waves = 0, max_cars = 0; // (first measurement, gpurun_out/r03a: the fused form is slower at every size -- AUTO stays classic)
+    if (env) {
+        char *e = nullptr;
+        waves = (int)strtol(env, &e, 10);
+        if (e && *e == ':') max_cars = (int)strtol(e + 1, nullptr, 10);
+    }
+    if (h->group_waves) waves = h->group_waves;
+    if (h->step_path == F110_PATH_GROUP) max_cars = 0x7fffffff;
+    else if (env && waves == 0) return 0; // F110_GROUP=0: classic everywhere
+    if (n_cars > max_cars) return 0;
+    if (waves == 0) waves = n_cars <= 1024 ? 8 : 4;
+    waves = std::max(1, std::min(GROUP_MAX_WAVES, waves));
+    return waves;
+}
+
+template <int MODE>
+static int launch_group_t(f110_handle *h, const GroupArgs &a, int waves, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1)
+{
+    const dim3 grid(a.s.n_cars), block(waves * WAVE);
+#define F110_GROUP_LAUNCH(I, P)                                                                                    \
+    do {                                                                                                           \
+        if (ev0 || ev1) hipExtLaunchKernelGGL((car_group_kernel<I, P, MODE>), grid, block, 0, st, ev0, ev1, 0, a);  \
+        else hipLaunchKernelGGL((car_group_kernel<I, P, MODE>), grid, block, 0, st, a);                             \
+    } while (0)
+    if (h->ident && h->pow2) F110_GROUP_LAUNCH(true, true);
+    else if (h->ident) F110_GROUP_LAUNCH(true, false);
+    else if (h->pow2) F110_GROUP_LAUNCH(false, true);
+    else F110_GROUP_LAUNCH(false, false);
+#undef F110_GROUP_LAUNCH
+    HIP_TRY(hipGetLastError());
+    return F110_OK;
+}
+
+static int launch_group(f110_handle *h, const GroupArgs &a, int mode, int waves, hipStream_t st, hipEvent_t ev0 = nullptr,
+                        hipEvent_t ev1 = nullptr)
+{
+    if (a.s.n_cars < 1 || waves < 1 || waves > GROUP_MAX_WAVES) return fail(F110_E_INVALID, "car-group launch: %d cars, %d waves per car", a.s.n_cars, waves);
+    if (mode == 2 && a.s.agents != 1) return fail(F110_E_INVALID, "the fused step needs num_agents == 1");
+    return mode == 2 ? launch_group_t<2>(h, a, waves, st, ev0, ev1)
+         : mode == 1 ? launch_group_t<1>(h, a, waves, st, ev0, ev1) : launch_group_t<0>(h, a, waves, st, ev0, ev1);
 }
 
 static int run_step(f110_handle *h, const double *actions, int reset_only, hipStream_t st)
@@ -845,6 +933,35 @@ static int run_step(f110_handle *h, const double *actions, int reset_only, hipSt
     const f110_config &c = h->cfg;
     const f110_buffers &b = h->bufs;
     const int N = c.num_envs * c.num_agents;
+    const int gw = group_waves_for(h, N);
+    const bool prof = h->prof_on && (size_t)(2 * h->prof_n + 1) < h->prof_ev.size();
+    hipEvent_t ev0 = prof ? h->prof_ev[2 * h->prof_n] : nullptr, ev1 = prof ? h->prof_ev[2 * h->prof_n + 1] : nullptr;
+    GroupArgs g;
+    memset(&g, 0, sizeof(g));
+    if (gw) {
+        ScanArgs &s = g.s;
+        s.maps = h->d_maps; s.env_map = h->multi ? h->d_env_map : nullptr; s.scan = scan_dev(h); s.n_cars = N; s.agents = c.num_agents;
+        s.pose_src = b.state; s.pose_stride = 7; s.yaw_off = 4;
+        s.state = b.state; s.noise_step = b.noise_step; s.chunk_beam0 = h->d_chunk0;
+        s.noise_side = h->d_noise_side; s.noise_T = h->noise_T > 0 ? h->noise_T : 1;
+        s.beam_cosines = h->d_beam_cosines; s.ttc_thresh = c.ttc_thresh;
+        s.in_collision = b.in_collision; s.pending_reset = b.pending_reset; s.reset_only = reset_only;
+        s.out_f32 = b.scans; s.out_f64 = b.scans_f64; s.lookups = b.lookups;
+    }
+    if (gw && c.num_agents == 1) {
+        // the whole step of every env in ONE launch (car_group_kernel MODE 2)
+        FuseArgs &f = g.f;
+        f.state = b.state; f.steer_buf = b.steer_buf; f.steer_cnt = b.steer_cnt; f.noise_step = b.noise_step; f.actions = actions;
+        f.spawn = b.spawn; f.pending_reset = b.pending_reset; f.pose_snap = b.pose_snap; f.in_collision = b.in_collision;
+        f.agent_params = h->d_agent_params; f.time_step = c.timestep; f.integrator = c.integrator; f.autoreset = c.autoreset;
+        f.collisions = b.collisions; f.collision_idx = b.collision_idx; f.start_rot = b.start_rot; f.near_start = b.near_start;
+        f.toggles = b.toggles; f.lap_counts = b.lap_counts; f.lap_times = b.lap_times; f.current_time = b.current_time;
+        f.done = b.done; f.checkpoint_done = b.checkpoint_done;
+        int rc = launch_group(h, g, 2, gw, st, ev0, ev1);
+        if (rc) return rc;
+        if (prof) h->prof_n++;
+        return F110_OK;
+    }
     DynArgs d;
     d.n_cars = N; d.agents = c.num_agents; d.state = b.state; d.steer_buf = b.steer_buf; d.steer_cnt = b.steer_cnt;
     d.noise_step = b.noise_step; d.actions = actions; d.spawn = b.spawn; d.pending_reset = b.pending_reset;
@@ -853,18 +970,21 @@ static int run_step(f110_handle *h, const double *actions, int reset_only, hipSt
     hipLaunchKernelGGL(dynamics_kernel, dim3((N + 255) / 256), dim3(256), 0, st, d);
     HIP_TRY(hipGetLastError());
 
-    ScanArgs s;
-    memset(&s, 0, sizeof(s));
-    s.maps = h->d_maps; s.env_map = h->multi ? h->d_env_map : nullptr; s.scan = scan_dev(h); s.n_cars = N; s.agents = c.num_agents;
-    s.pose_src = b.state; s.pose_stride = 7; s.yaw_off = 4;
-    s.state = b.state; s.noise_step = b.noise_step; s.chunk_beam0 = h->d_chunk0;
-    s.noise_side = h->d_noise_side; s.noise_T = h->noise_T > 0 ? h->noise_T : 1;
-    s.beam_cosines = h->d_beam_cosines;
-    s.ttc_thresh = c.ttc_thresh;
-    s.in_collision = b.in_collision; s.pending_reset = b.pending_reset; s.reset_only = reset_only;
-    s.out_f32 = b.scans; s.out_f64 = b.scans_f64; s.lookups = b.lookups;
-    const bool prof = h->prof_on && (size_t)(2 * h->prof_n + 1) < h->prof_ev.size();
-    int rc = prof ? launch_scan(h, s, st, h->prof_ev[2 * h->prof_n], h->prof_ev[2 * h->prof_n + 1]) : launch_scan(h, s, st);
+    int rc;
+    if (gw) rc = launch_group(h, g, 1, gw, st, ev0, ev1);
+    else {
+        ScanArgs s;
+        memset(&s, 0, sizeof(s));
+        s.maps = h->d_maps; s.env_map = h->multi ? h->d_env_map : nullptr; s.scan = scan_dev(h); s.n_cars = N; s.agents = c.num_agents;
+        s.pose_src = b.state; s.pose_stride = 7; s.yaw_off = 4;
+        s.state = b.state; s.noise_step = b.noise_step; s.chunk_beam0 = h->d_chunk0;
+        s.noise_side = h->d_noise_side; s.noise_T = h->noise_T > 0 ? h->noise_T : 1;
+        s.beam_cosines = h->d_beam_cosines;
+        s.ttc_thresh = c.ttc_thresh;
+        s.in_collision = b.in_collision; s.pending_reset = b.pending_reset; s.reset_only = reset_only;
+        s.out_f32 = b.scans; s.out_f64 = b.scans_f64; s.lookups = b.lookups;
+        rc = launch_scan(h, s, st, ev0, ev1);
+    }
     if (rc) return rc;
     if (prof) h->prof_n++;
     if (c.num_agents > 1) {
@@ -935,7 +1055,29 @@ extern "C" int f110_step(f110_handle *h, const double *actions, void *stream)
 extern "C" int f110_set_scan_stages(f110_handle *h, const char *spec)
 {
     if (!h) return fail(F110_E_INVALID, "f110_set_scan_stages: null handle");
+    if (spec && *spec) {
+        std::vector<StageSpec> parsed;
+        const char *why = nullptr;
+        if (!parse_stage_spec(spec, parsed, &why)) return fail(F110_E_INVALID, "f110_set_scan_stages: \"%s\": %s", spec, why);
+        long long fixed = 0;
+        for (const StageSpec &x : parsed) if (x.cars > 0) fixed += x.cars;
+        if (fixed > (long long)h->cfg.num_envs * h->cfg.num_agents)
+            return fail(F110_E_INVALID, "f110_set_scan_stages: \"%s\" names %lld cars, the handle has %d", spec, fixed, h->cfg.num_envs * h->cfg.num_agents);
+    }
     h->stages = spec ? spec : "";
+    h->epoch++;
+    return F110_OK;
+}
+
+extern "C" int f110_set_step_path(f110_handle *h, int32_t path, int32_t waves_per_car)
+{
+    if (!h) return fail(F110_E_INVALID, "f110_set_step_path: null handle");
+    if (path != F110_PATH_AUTO && path != F110_PATH_CLASSIC && path != F110_PATH_GROUP)
+        return fail(F110_E_INVALID, "f110_set_step_path: path %d (0 auto, 1 classic, 2 car groups)", path);
+    if (waves_per_car < 0 || waves_per_car > GROUP_MAX_WAVES)
+        return fail(F110_E_INVALID, "f110_set_step_path: %d wavefronts per car (0 = built-in choice, 1..%d)", waves_per_car, GROUP_MAX_WAVES);
+    h->step_path = path;
+    h->group_waves = waves_per_car;
     h->epoch++;
     return F110_OK;
 }
@@ -1019,6 +1161,12 @@ extern "C" int f110_scan(f110_handle *h, const double *poses, int32_t n, double 
     s.maps = h->d_maps; s.scan = scan_dev(h); s.n_cars = n; s.agents = 1;
     s.pose_src = poses; s.pose_stride = 3; s.yaw_off = 2;
     s.out_f32 = out32; s.out_f64 = out64; s.lookups = lookups; s.noise_T = 1; s.chunk_beam0 = h->d_chunk0;
+    if (const int gw = group_waves_for(h, n)) {
+        GroupArgs g;
+        memset(&g, 0, sizeof(g));
+        g.s = s;
+        return launch_group(h, g, 0, gw, (hipStream_t)stream);
+    }
     return launch_scan(h, s, (hipStream_t)stream);
 }
 

@@ -146,11 +146,7 @@ __device__ inline double dist_lookup(const MapView &m, const double *lds_lut, do
     // a finished ray presents an out-of-range offset: the hardware range check answers 0
     // (= LDS offset 0 = distance 0.0, which parks the ray: total += 0, x += 0*c) without
     // occupying the L1 tag pipeline
-#if !defined(F110_NO_PARK)
     off = live ? off : 0xffffffffu;
-#else
-    (void)live; // variant: finished rays keep reading their last cell (d = 0 there, or total already past max_range)
-#endif
     // buffer load: 32-bit per-lane offset against a scalar descriptor
     const unsigned code = (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(m.cells_rsrc, (int)off, 0, 0);
     // common case: the loaded value IS the LDS byte offset of the distance: one ds_read_b64
@@ -221,8 +217,8 @@ struct ScanArgs {
     // Wave -> (car, part) mapping: consecutive STAGES of cars, stage s giving each of its stage_cars[s] cars
     // 2^stage_log2w[s] waves (launch_scan explains the choice).  Read through `rare`, not held in registers.
     int n_stages;
-    int stage_cars[8];
-    int stage_log2w[8];
+    int stage_cars[8];          // SCAN_MAX_STAGES
+    int stage_log2w[8];         // each 0..SCAN_MAX_LOG2W
     // pose source: pose = (src[car*stride], src[car*stride+1], src[car*stride+yaw_off])
     const double *pose_src;
     int pose_stride, yaw_off;
@@ -249,6 +245,16 @@ struct ScanArgs {
 // use is the 8 KiB distance LUT shared by the workgroup, so occupancy is register-bound.
 // STEP: full env step (noise + iTTC + state update); false: ScanSimulator2D.scan(pose, None).
 constexpr int MAX_CHUNKS = 64; // beams are handed out in chunks of 64 (num_beams <= 4096)
+
+// scan_kernel re-reads its argument block through the kernarg segment pointer, which is only the same block
+// if ScanArgs is the kernel's ONLY argument, passed by value at offset 0, and trivially copyable (the launch
+// memcpy's it).  The stage list is a fixed array inside it: launch_scan checks the count and the exponents.
+constexpr int SCAN_MAX_STAGES = 8, SCAN_MAX_LOG2W = 3;
+static_assert(__is_trivially_copyable(ScanArgs), "ScanArgs is copied into the kernarg segment byte for byte");
+static_assert(offsetof(ScanArgs, maps) == 0, "kernarg re-read assumes the argument block starts with ScanArgs");
+static_assert(sizeof(((ScanArgs *)0)->stage_cars) == SCAN_MAX_STAGES * sizeof(int) &&
+              sizeof(((ScanArgs *)0)->stage_log2w) == SCAN_MAX_STAGES * sizeof(int), "stage list capacity");
+static_assert(sizeof(ScanArgs) <= 4096, "kernarg segment size");
 
 template <bool IDENT, bool POW2, bool STEP>
 #ifndef F110_SCAN_MIN_WAVES
@@ -377,23 +383,13 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
                 const bool take = k < nbl;
                 const int kk = take ? k : 0;
                 const int b = s_chunk0[(kk >> 6) * wpc + part] + (kk & 63);
-#if defined(F110_NOISE_AT_EMIT) // round-1 variant, kept for A/B runs
-                const unsigned pb16 = (unsigned)max(beam, 0) * 16u; // 32-bit byte offset: scalar base + VGPR offset
-                const double2 nsv = STEP ? *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(ns) + (size_t)pb16)
-                                         : make_double2(0.0, 0.0);
-                const double nzv = nsv.x, sdv = nsv.y;
-#else
                 const double2 nsv = STEP ? *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(ns) + (size_t)((unsigned)b * 16u))
                                          : make_double2(0.0, 0.0);
                 const double nzv = nz, sdv = sd;
-#endif
                 const int ti = beam_theta_index(T0, t0w, b, a.scan);
                 const double2 cs = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(a.scan.cs) + (size_t)((unsigned)ti * 16u)); // second round trip, overlapped with emit()
                 if (beam >= 0) emit(beam, total, nzv, sdv);
                 beam = -1;
-#if defined(F110_NO_PARK)
-                total = __builtin_inf(); // a lane without a ray must stay inactive (total <= max_range fails)
-#endif
                 if (take) {
                     c = cs.x;
                     s = cs.y;
@@ -401,30 +397,19 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
                     y = py + d0 * s;
                     total = d0;
                     beam = b;
-#if !defined(F110_NOISE_AT_EMIT)
                     nz = nsv.x;
                     sd = nsv.y;
-#endif
                     active = true;
                 }
             }
             next += nidle;
-#if defined(F110_COUNT_MODE) && F110_COUNT_MODE == 2 // diagnostics: refills
-            nlook += 1;
-#endif
             int nact = __popcll(vote(active));
             if (nact == 0) break;
             // ---- march phase: every lane steps (idle lanes are parked by d = 0) until
             // enough lanes are idle again or, once no beams are left, the wave has drained ----
             const int go = next < nbl ? WAVE - REFILL_MIN_IDLE : 0; // keep marching while nact > go
             do {
-#if !defined(F110_COUNT_MODE)
                 nlook += (unsigned)nact;
-#elif F110_COUNT_MODE == 1   // diagnostics: wave iterations
-                nlook += 1;
-#elif F110_COUNT_MODE == 3   // diagnostics: wave iterations of the drain phase
-                nlook += go == 0 ? 1 : 0;
-#endif
                 const double d = dist_lookup<IDENT, POW2>(mv, s_lut, x, y, active);
                 total += d;
                 x += d * c;
@@ -444,6 +429,304 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
     if (STEP) {
         if (vote(hit) != 0ull && lane == 0) ra->in_collision[car] = 1;
     }
+}
+
+// ------------------------------------------------------------------ car-group kernel (small launches)
+// scan_kernel gives a car ONE wavefront (or a fixed slice of the beam queue per wave): right when 8 192 waves fill the
+// chip several times over, wrong for a few thousand cars -- the chip is then underfilled, a launch lasts as long as
+// its slowest whole-car wave, and the two small kernels around the scan (dynamics, env bookkeeping) are a fifth of the
+// step.  Here ONE WORKGROUP of 2..8 wavefronts serves one car:
+//   * its waves draw beams from ONE queue (an LDS counter: `ds_add_rtn` per refill), so they finish together
+//     whatever the car's mix of long and short rays -- no static slices, no slice whose rays happen to be long;
+//   * MODE 2 (A == 1) is the WHOLE env step in one launch: wave 0 integrates the car (RaceCar.update_pose: steer
+//     FIFO, PID, RK4, yaw wrap -- or the reset + zero action of F110Env.reset) from the OLD state while the other waves
+//     stage the distance LUT, and hands the new state over through LDS; the last wave of the group to finish its rays
+//     (LDS arrival counter, which also carries the iTTC hits) writes the state back -- nobody in the group reads the
+//     old state after the barrier, no other group ever reads it -- and does the env bookkeeping of env_kernel
+//     (collision flags, iTTC zeroing, noise row, lap logic, done, autoreset).  No GJK at A == 1.
+// Results are those of dynamics_kernel -> scan_kernel -> env_kernel bit for bit: a beam's value does not depend on
+// the lane that marched it, and the device functions are shared.
+constexpr int GROUP_MAX_WAVES = 8;
+
+__device__ inline bool check_done_dev(const double *xy, int stride, const double *start, int A, double r00, double r01,
+                                      double r10, double r11, double current_time, uint8_t *near_start, int32_t *toggles,
+                                      int32_t *lap_counts, double *lap_times, uint8_t *checkpoint_done); // (below)
+
+struct FuseArgs {               // MODE 2 only: what dynamics_kernel and env_kernel take
+    double *state;              // [N,7]
+    double *steer_buf;          // [N,2]
+    int32_t *steer_cnt;         // [N]
+    int32_t *noise_step;        // [N]
+    const double *actions;      // [N,2] or NULL (reset)
+    const double *spawn;        // [N,3]
+    uint8_t *pending_reset;     // [B]
+    double *pose_snap;          // [N,3]
+    uint8_t *in_collision;      // [N]
+    const Params *agent_params;
+    double time_step;
+    int integrator, autoreset;
+    uint8_t *collisions;        // [N]
+    int32_t *collision_idx;     // [N]
+    double *start_rot;          // [B,4]
+    uint8_t *near_start;        // [N]
+    int32_t *toggles;           // [N]
+    int32_t *lap_counts;        // [N]
+    double *lap_times;          // [N]
+    double *current_time;       // [B]
+    uint8_t *done;              // [B]
+    uint8_t *checkpoint_done;   // [N] or NULL
+};
+
+struct GroupArgs {
+    ScanArgs s;                 // wpc / stage list unused: the grid is one workgroup per car
+    FuseArgs f;
+};
+static_assert(__is_trivially_copyable(GroupArgs) && offsetof(GroupArgs, s) == 0 && sizeof(GroupArgs) <= 4096,
+              "car_group_kernel re-reads its only argument through the kernarg segment pointer");
+
+// a wave-uniform double held in VGPRs -> SGPRs
+__device__ inline double uniform_f64(double v)
+{
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+// MODE 0: ScanSimulator2D.scan(pose, None); 1: the scan of a step (noise, iTTC flag); 2: the whole step (A == 1)
+template <bool IDENT, bool POW2, int MODE>
+__global__ __launch_bounds__(GROUP_MAX_WAVES * WAVE, 8) void car_group_kernel(GroupArgs a)
+{
+    constexpr bool STEP = MODE >= 1, FUSED = MODE == 2;
+    __shared__ __attribute__((aligned(16))) double s_lut[LUT_LDS];
+    __shared__ int s_chunk0[MAX_CHUNKS];
+    __shared__ unsigned s_next;     // head of the car's beam queue
+    __shared__ unsigned s_arrive;   // waves that have finished their rays (+ 0x10000 per wave with an iTTC hit)
+    __shared__ double s_car[12];    // FUSED: new state [7], steer FIFO [2], FIFO count, noise row
+    __shared__ double s_rk[FUSED ? 14 : 1]; // FUSED: update_pose_compact's between-stage vectors
+#if defined(__HIP_DEVICE_COMPILE__)
+    const GroupArgs *rare = (const GroupArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+#else
+    const GroupArgs *rare = &a; // host pass of the single-source compile: never executed
+#endif
+    const int nb = a.s.scan.nb;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int nthreads = blockDim.x, nwaves = nthreads >> 6;
+    const int car = blockIdx.x, env = car / a.s.agents;
+    bool pend = false; // (workgroup-uniform)
+    if (STEP) {
+        pend = a.s.pending_reset[env] != 0;
+        if (a.s.reset_only && !pend) return;
+    }
+    const MapDev &md = a.s.maps[a.s.env_map ? a.s.env_map[env] : 0];
+    {
+        const double2 *src = reinterpret_cast<const double2 *>(md.lut_lds);
+        double2 *dst = reinterpret_cast<double2 *>(s_lut);
+        for (int i = threadIdx.x; i < LUT_LDS / 2; i += nthreads) dst[i] = src[i];
+    }
+    for (int i = threadIdx.x; i < ((nb + 63) >> 6); i += nthreads) s_chunk0[i] = a.s.chunk_beam0[i];
+    if (threadIdx.x == 0) { s_next = 0; s_arrive = 0; }
+    if (FUSED && wave == 0) {
+        // RaceCar.update_pose (base_classes.py:254-402) from the OLD state, or RaceCar.reset (:181-202) followed by
+        // the zero-action step of F110Env.reset (f110_env.py:335-336): what dynamics_kernel does for this car
+        const FuseArgs *F = &rare->f;
+        asm volatile("" : "+s"(F));
+        double st[7], sb[2], steer, speed;
+        int sc, row;
+        if (pend) {
+#pragma unroll
+            for (int i = 0; i < 7; i++) st[i] = 0.;
+            st[0] = F->spawn[(size_t)car * 3];
+            st[1] = F->spawn[(size_t)car * 3 + 1];
+            st[4] = F->spawn[(size_t)car * 3 + 2];
+            sb[0] = sb[1] = 0.;
+            sc = 0; steer = 0.; speed = 0.; row = 0;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 7; i++) st[i] = F->state[(size_t)car * 7 + i];
+            sb[0] = F->steer_buf[(size_t)car * 2];
+            sb[1] = F->steer_buf[(size_t)car * 2 + 1];
+            sc = F->steer_cnt[car];
+            steer = F->actions[(size_t)car * 2];
+            speed = F->actions[(size_t)car * 2 + 1];
+            row = F->noise_step[car];
+        }
+        update_pose_compact(st, sb, sc, steer, speed, F->agent_params[0], F->time_step, F->integrator, s_rk);
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 7; i++) s_car[i] = st[i];
+            s_car[7] = sb[0]; s_car[8] = sb[1]; s_car[9] = (double)sc; s_car[10] = (double)row;
+        }
+    }
+    __syncthreads();
+    MapView mv;
+    mv.cells_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(md.cells), 0, (int)md.cells_bytes, 0x00020000);
+    mv.init(md);
+
+    double px, py, yaw, vel = 0.0;
+    int row = 0;
+    if (FUSED) {
+        px = uniform_f64(s_car[0]); py = uniform_f64(s_car[1]); yaw = uniform_f64(s_car[4]); vel = uniform_f64(s_car[3]);
+        row = __builtin_amdgcn_readfirstlane((int)s_car[10]);
+    } else {
+        px = a.s.pose_src[(size_t)car * a.s.pose_stride];
+        py = a.s.pose_src[(size_t)car * a.s.pose_stride + 1];
+        yaw = a.s.pose_src[(size_t)car * a.s.pose_stride + a.s.yaw_off];
+        if (STEP) { vel = a.s.state[(size_t)car * 7 + 3]; row = a.s.noise_step[car]; }
+    }
+    const double eps = a.s.scan.eps, max_range = a.s.scan.max_range;
+    const bool do_ttc = STEP && vel != 0.0;               // laser_models.py:206
+    const double cand = a.s.ttc_thresh * fabs(vel) * 1.000000001; // see scan_kernel
+    const double2 *__restrict__ ns = STEP ? a.s.noise_side + (size_t)((long long)row % a.s.noise_T) * nb : nullptr;
+    float *o32 = a.s.out_f32 ? a.s.out_f32 + (size_t)car * nb : nullptr;
+    double *o64 = a.s.out_f64 ? a.s.out_f64 + (size_t)car * nb : nullptr;
+    bool hit = false;
+
+    auto emit = [&](int i, double tot, double nzv, double sdv) {
+        double v = __builtin_fmin(tot, max_range);
+        if (STEP) v += nzv;
+        if (o32) *reinterpret_cast<float *>(reinterpret_cast<char *>(o32) + (size_t)((unsigned)i * 4u)) = (float)v;
+        if (o64) *reinterpret_cast<double *>(reinterpret_cast<char *>(o64) + (size_t)((unsigned)i * 8u)) = v;
+        if (do_ttc) {
+            const double sd = v - sdv;
+            if (__builtin_expect(fabs(sd) < cand, 0)) {
+                const GroupArgs *ra = rare;
+                asm volatile("" : "+s"(ra));
+                const double proj_vel = vel * ra->s.beam_cosines[i];
+                const double ttc = sd / proj_vel;
+                if ((ttc < ra->s.ttc_thresh) && (ttc >= 0.0)) hit = true;
+            }
+        }
+    };
+
+    const double d0 = dist_lookup<IDENT, POW2>(mv, s_lut, px, py, true);
+    unsigned nlook = 0;
+    if (!(d0 > eps && d0 <= max_range)) {
+        for (int i = threadIdx.x; i < nb; i += nthreads) {
+            const double2 v = STEP ? ns[i] : make_double2(0.0, 0.0);
+            emit(i, d0, v.x, v.y);
+        }
+        if (wave == 0) nlook = (unsigned)nb; // the reference reads the table once per beam
+    } else {
+        const double td = (double)a.s.scan.theta_dis;
+        double t0w = td * (yaw - a.s.scan.fov / 2.) / (2. * F110_PI);
+        t0w = fmod_small(t0w, td);
+        while (t0w < 0) t0w += td;
+        const unsigned long long T0 = (t0w >= 0 && t0w < td) ? (unsigned long long)(t0w * 1099511627776.0) : ~0ull;
+
+        bool exhausted = false; // wave-uniform: the car's queue has been handed out
+        bool active = false;
+        int beam = -1;
+        double x = px, y = py, c = 0, s = 0, total = 0;
+        double nz = 0, sd = 0;
+        for (;;) {
+            const unsigned long long idle = vote(!active);
+            const int nidle = __popcll(idle);
+            int base = nb;
+            if (!exhausted) {
+                unsigned b0 = 0;
+                if (lane == 0) b0 = atomicAdd(&s_next, (unsigned)nidle);
+                base = __builtin_amdgcn_readfirstlane((int)b0);
+                exhausted = base + nidle >= nb;
+            }
+            if (!active) {
+                const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32),
+                                    __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
+                const int k = base + rank;
+                const bool take = k < nb;
+                const int kk = take ? k : 0;
+                const int b = s_chunk0[kk >> 6] + (kk & 63);
+                const double2 nsv = STEP ? *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(ns) + (size_t)((unsigned)b * 16u))
+                                         : make_double2(0.0, 0.0);
+                const double nzv = nz, sdv = sd;
+                const int ti = beam_theta_index(T0, t0w, b, a.s.scan);
+                const double2 cs = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(a.s.scan.cs) + (size_t)((unsigned)ti * 16u));
+                if (beam >= 0) emit(beam, total, nzv, sdv);
+                beam = -1;
+                if (take) {
+                    c = cs.x;
+                    s = cs.y;
+                    x = px + d0 * c;
+                    y = py + d0 * s;
+                    total = d0;
+                    beam = b;
+                    nz = nsv.x;
+                    sd = nsv.y;
+                    active = true;
+                }
+            }
+            int nact = __popcll(vote(active));
+            if (nact == 0) break;
+            nlook += (unsigned)min(max(nb - base, 0), nidle); // first read of every beam taken (at the car itself)
+            const int go = exhausted ? 0 : WAVE - REFILL_MIN_IDLE;
+            do {
+                nlook += (unsigned)nact;
+                const double d = dist_lookup<IDENT, POW2>(mv, s_lut, x, y, active);
+                total += d;
+                x += d * c;
+                y += d * s;
+                const bool c1 = d > eps, c2 = total <= max_range;
+                active = c1 && c2;
+                nact = __popcll(vote(c1) & vote(c2));
+            } while (nact > go);
+        }
+    }
+    const GroupArgs *ra = rare;
+    asm volatile("" : "+s"(ra));
+    if (ra->s.lookups && lane == 0 && nlook) atomicAdd(&ra->s.lookups[car], nlook);
+    if (!STEP) return;
+    const bool whit = vote(hit) != 0ull;
+    if (!FUSED) {
+        // the flag only; env_kernel zeroes the state.  Plain store: all writers store the same 1.
+        if (whit && lane == 0) ra->s.in_collision[car] = 1;
+        return;
+    }
+    // ---- FUSED: the last wave of the group to get here closes the car's step (env_kernel for A == 1)
+    unsigned old = 0;
+    if (lane == 0) old = atomicAdd(&s_arrive, 1u | (whit ? 0x10000u : 0u));
+    old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
+    if ((int)(old & 0xffffu) != nwaves - 1) return;
+    if (lane != 0) return;
+    const bool anyhit = whit || (old >> 16) != 0u;
+    const FuseArgs *F = &ra->f;
+    double st[7];
+#pragma unroll
+    for (int i = 0; i < 7; i++) st[i] = s_car[i];
+    F->pose_snap[(size_t)car * 3] = st[0];       // poses after integration, before iTTC zeroing (base_classes.py:567)
+    F->pose_snap[(size_t)car * 3 + 1] = st[1];
+    F->pose_snap[(size_t)car * 3 + 2] = st[4];
+    if (anyhit) { st[3] = 0.; st[4] = 0.; st[5] = 0.; st[6] = 0.; } // check_ttc, base_classes.py:244-247
+#pragma unroll
+    for (int i = 0; i < 7; i++) F->state[(size_t)car * 7 + i] = st[i];
+    F->steer_buf[(size_t)car * 2] = s_car[7];
+    F->steer_buf[(size_t)car * 2 + 1] = s_car[8];
+    F->steer_cnt[car] = (int)s_car[9];
+    F->noise_step[car] = (int)s_car[10] + 1;      // one noise row consumed per scan
+    F->in_collision[car] = anyhit ? 1 : 0;
+    F->collisions[car] = anyhit ? 1 : 0;          // no other car: Simulator.check_collision finds nothing (:529-543), :581-582
+    F->collision_idx[car] = -1;
+    double ct = F->current_time[env];
+    double r00, r01, r10, r11;
+    if (pend) {
+        // F110Env.reset (f110_env.py:318-329)
+        ct = 0.0;
+        const double th = -F->spawn[(size_t)car * 3 + 2];
+        r00 = cos(th); r01 = -sin(th); r10 = sin(th); r11 = cos(th);
+        F->start_rot[(size_t)env * 4] = r00; F->start_rot[(size_t)env * 4 + 1] = r01;
+        F->start_rot[(size_t)env * 4 + 2] = r10; F->start_rot[(size_t)env * 4 + 3] = r11;
+        F->near_start[car] = 1; F->toggles[car] = 0;
+    } else {
+        r00 = F->start_rot[(size_t)env * 4]; r01 = F->start_rot[(size_t)env * 4 + 1];
+        r10 = F->start_rot[(size_t)env * 4 + 2]; r11 = F->start_rot[(size_t)env * 4 + 3];
+    }
+    ct = ct + F->time_step; // f110_env.py:293
+    F->current_time[env] = ct;
+    const bool all_done = check_done_dev(st, 7, F->spawn + (size_t)car * 3, 1, r00, r01, r10, r11, ct, F->near_start + car,
+                                         F->toggles + car, F->lap_counts + car, F->lap_times + car,
+                                         F->checkpoint_done ? F->checkpoint_done + car : nullptr);
+    const bool dn = anyhit || all_done;
+    F->done[env] = dn ? 1 : 0;
+    F->pending_reset[env] = (F->autoreset && dn) ? 1 : 0;
 }
 
 // ------------------------------------------------------------------ opponents (A > 1)

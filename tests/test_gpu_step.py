@@ -14,6 +14,15 @@ def _np(t):
     return t.detach().cpu().numpy()
 
 
+@pytest.fixture(autouse=True, params=['classic', 'group'])
+def step_path(request, monkeypatch):
+    """Every test of this module runs on both step paths (f110_set_step_path): 'classic' = dynamics_kernel ->
+    scan_kernel -> [opponents] -> env_kernel, 'group' = a workgroup per car (the whole step in ONE launch for one
+    agent).  The engine reads F110_STEP_PATH when it is built."""
+    monkeypatch.setenv('F110_STEP_PATH', request.param)
+    return request.param
+
+
 def _mk_oracle_env(assets, A, noise_steps, integrator=oracle.RK4):
     sc = oracle.Scanner(1080, 2 * np.pi)
     sc.set_map(os.path.join(assets, 'example_map.yaml'), '.png')
@@ -492,6 +501,7 @@ def test_scan_stage_lists_give_identical_results(assets, spec, A):
     acts = torch.as_tensor(workload.action_pool(8, B, A), device='cuda')
     e1 = _vec(assets, B, A, autoreset=True, count_lookups=True)
     e2 = _vec(assets, B, A, autoreset=True, count_lookups=True)
+    e1.eng.set_step_path('classic'); e2.eng.set_step_path('classic')
     e2.eng.set_scan_stages(spec)
     e1.reset(poses); e2.reset(poses)
     keys = ('scans_f64', 'scans', 'state', 'lookups', 'collisions', 'in_collision', 'toggles', 'done', 'noise_step')
@@ -510,6 +520,62 @@ def test_scan_stage_lists_give_identical_results(assets, spec, A):
     b64, b32, blk = e2.eng.scan(ps, want_f32=True, want_lookups=True)
     assert torch.equal(a64, b64) and torch.equal(a32, b32) and torch.equal(alk, blk)
     e1.close(); e2.close()
+
+
+@pytest.mark.parametrize('waves', [1, 2, 3, 4, 8])
+@pytest.mark.parametrize('A', [1, 2])
+def test_step_paths_give_identical_results(assets, waves, A):
+    """The car-group path (one workgroup of `waves` wavefronts per car drawing beams from one queue; for one agent the
+    whole step -- update_pose in front, env bookkeeping behind -- in that one launch) against the classic three-kernel
+    path: every buffer a step writes `==` over 60 autoreset steps with wall hits, cars inside walls / off the map and
+    a masked reset in between; then the function-level scan."""
+    import torch
+    from red_gym_amd import workload
+    B, T = 37, 60
+    poses = workload.spawn_poses(B, A)
+    poses[3, 0, :2] = [0.0, 20.0]
+    poses[17, A - 1, :2] = [-78.0, -44.0]
+    poses[18, 0, :2] = [500.0, 500.0]
+    acts = workload.action_pool(8, B, A)
+    acts[:, 5:12, :, 0] = 0.35    # some envs steer into the wall at speed: iTTC hits, autoreset
+    acts[:, 5:12, :, 1] = 7.0
+    acts = torch.as_tensor(acts, device='cuda')
+    e1 = _vec(assets, B, A, autoreset=True, count_lookups=True)
+    e2 = _vec(assets, B, A, autoreset=True, count_lookups=True)
+    e1.eng.set_step_path('classic')
+    e2.eng.set_step_path('group', waves)
+    e1.reset(poses); e2.reset(poses)
+    keys = [k for k in e1.eng.t if e1.eng.t[k] is not None]
+    hits = 0
+    for k in range(T):
+        e1.step(acts[k % 8]); e2.step(acts[k % 8])
+        if k == 30:
+            m = torch.zeros(B, dtype=torch.uint8, device='cuda'); m[::3] = 1
+            e1.reset(poses, m); e2.reset(poses, m)
+        for key in keys:
+            assert torch.equal(e1.eng.t[key], e2.eng.t[key]), (k, key)
+        hits += int(e1.eng.t['done'].sum())
+    assert hits > 0
+    rng = np.random.default_rng(5)
+    ps = np.concatenate([workload.spawn_poses(37, 1)[:, 0], rng.uniform(-120, 120, (6, 3))])
+    a64, a32, alk = e1.eng.scan(ps, want_f32=True, want_lookups=True)
+    b64, b32, blk = e2.eng.scan(ps, want_f32=True, want_lookups=True)
+    assert torch.equal(a64, b64) and torch.equal(a32, b32) and torch.equal(alk, blk)
+    e1.close(); e2.close()
+
+
+def test_set_scan_stages_refuses_malformed_lists(assets):
+    env = _vec(assets, 8, 1)
+    for bad in ('x', '4', '*:9', '*:0,*:1', '4:0:1', '1:0,1:0,1:0,1:0,1:0,1:0,*:0', '100:0,*:1', '*:-1', '2:0,'):
+        if bad == '4':
+            continue  # "4 cars, whole waves, the rest whole": legal
+        with pytest.raises(ValueError):
+            env.eng.set_scan_stages(bad)
+    env.eng.set_scan_stages('4:1,*:0')
+    env.eng.set_scan_stages(None)
+    with pytest.raises(ValueError):
+        env.eng.set_step_path('group', 9)
+    env.close()
 
 
 @pytest.mark.parametrize('seed', list(range(32)))
