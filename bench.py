@@ -233,9 +233,13 @@ def main(argv=None):
     ap.add_argument('--bitmap', choices=['none', 'FILL', 'POLYGON', 'RAYS'], default='none',
                     help="secondary mode: also draw every ego scan to a 256x256 bird's-eye bitmap after each step "
                          '(lidar_to_bitmap, what the RL consumers do with the scans)')
-    ap.add_argument('--spinup', type=int, default=150,
-                    help='untimed steps BEFORE reset + warmup that only bring the GPU out of its idle power state '
-                         '(an idle MI355X needs ~25 ms of load to reach its clocks: tools/step_ramp.py); 0 = none')
+    ap.add_argument('--spinup', type=int, default=0,
+                    help='EXTRA untimed steps before reset + warmup (an idle MI355X needs ~25 ms of load to reach its '
+                         'clocks: tools/step_ramp.py).  0 (default): the protocol is exactly W warm-up + K timed steps; '
+                         'the effect of the clock ramp is reported separately as `sustained`')
+    ap.add_argument('--sustained', type=int, default=200,
+                    help='after the timed region, time this many further steps (clocks up, cars scattered) and report '
+                         'them as `sustained` beside `value` (0 = skip); never part of `value`')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-scan-events', action='store_true',
                     help='do not bracket the scan kernel with hipEvents (roofline becomes null)')
@@ -275,10 +279,11 @@ def main(argv=None):
     poses_np, acts_np = rank_workload(rank, B, A, POOL)
     poses = torch.as_tensor(poses_np, device=dev)
     acts = torch.as_tensor(acts_np, device=dev)  # resident in HBM before the timed region
-    # Spin-up: the first ~30 steps after an idle period run up to 15 % slower (0.80 -> 0.69 ms) whatever the env
-    # state, a third run right behind a second shows no ramp (profiles/r02_step_ramp.txt): it is the GPU leaving its
-    # idle power state.  A short run (--steps 20 --warmup 5) would measure mostly that, so the device is kept busy
-    # with throw-away steps first; the protocol proper -- reset, W warm-up steps, K timed steps -- follows without a gap.
+    # The first ~30 steps after an idle period run up to 15 % slower (0.80 -> 0.69 ms) whatever the env state
+    # (profiles/r02_step_ramp.txt: the GPU leaving its idle power state), so a short run (--steps 20 --warmup 5)
+    # measures mostly that ramp.  `value` is nevertheless the protocol as asked -- reset, W warm-up steps, K timed
+    # steps, nothing else -- and the figure with the clocks up is reported beside it (`sustained`, below).
+    # --spinup N > 0 (not the default) runs N throw-away steps first, for experiments.
     if args.spinup > 0:
         env.reset(poses)
         for k in range(args.spinup):
@@ -312,14 +317,22 @@ def main(argv=None):
     if not args.no_scan_events:
         env.eng.profile_begin(K)  # hipEvent pair around each of the K timed scan launches
     elapsed = timed_steps(ranks, step_fn, K)
+    scan_prof = env.eng.profile_end() if not args.no_scan_events else None  # the K timed launches only
+    tot_lookups = int(lookups.to(torch.int64).sum().item())                  # ... and their table reads
+    sustained = None
+    if args.sustained > 0:
+        el2 = timed_steps(ranks, lambda k: step_fn(K + k), args.sustained)
+        sustained = {'value': world * B * args.sustained / el2, 'unit': 'env-steps/s', 'steps': args.sustained,
+                     'ms_per_step': el2 / args.sustained * 1e3,
+                     'note': 'the %d steps right after the timed region (GPU clocks up, cars scattered by random '
+                             'driving); not part of `value`' % args.sustained}
 
     out = None
     if rank == 0:
         value = world * B * K / elapsed
         roof = None
         if not args.no_scan_events:
-            scan_ms, n_launch = env.eng.profile_end()
-            tot_lookups = int(lookups.to(torch.int64).sum().item())
+            scan_ms, n_launch = scan_prof
             cars = B * A
             # SURVEY 8(d) byte model, per car-step: L*4 + 1080*4 + 72
             bytes_per_launch = (tot_lookups / max(n_launch, 1)) * 4.0 + cars * (1080 * 4 + 72)
@@ -359,7 +372,7 @@ def main(argv=None):
                                          + ('' if args.bitmap == 'none' else '; + %s bitmap of every ego scan' % args.bitmap)),
                           'envs_per_gpu': B, 'agents': A, 'num_beams': 1080, 'map': 'example_map',
                           'sharding': 'independent env shards, no collective on the step path'},
-               'roofline': roof}
+               'roofline': roof, 'sustained': sustained}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(A)
     env.close()

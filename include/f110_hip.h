@@ -207,6 +207,20 @@ int f110_set_step_path(f110_handle *h, int32_t path, int32_t waves_per_car);
  * f110_launch_epoch still reports e; after that it must be re-captured (F110VecEnv.step_graph does so itself). */
 int f110_launch_epoch(f110_handle *h, int64_t *epoch);
 
+/* The step as a HIP graph the library builds itself, for callers without a capturing framework and as the reference
+ * point for framework captures: F110_GRAPH_NODES = one kernel node per kernel of f110_step(actions_dev), chained
+ * (hipGraphAddKernelNode); F110_GRAPH_CAPTURE = the same launches captured on a private non-blocking stream.
+ * f110_graph_launch enqueues one step on `stream` (the actions are read from actions_dev at execution time) and
+ * refuses a graph whose handle's launch epoch has moved (F110_E_INVALID: create it again).  f110_graph_info reports
+ * the node count and, with a path, writes the graph in dot form (hipGraphDebugDotPrint). */
+#define F110_GRAPH_NODES 0
+#define F110_GRAPH_CAPTURE 1
+typedef struct f110_graph f110_graph;
+int f110_graph_create(f110_handle *h, const double *actions_dev, int32_t how, f110_graph **out);
+int f110_graph_launch(f110_graph *g, void *stream);
+int f110_graph_info(f110_graph *g, int32_t *nodes, const char *dot_path);
+void f110_graph_destroy(f110_graph *g);
+
 /* Measurement aid (bench.py): between begin and end every f110_step attaches a start / stop
  * hipEvent pair to its scan_kernel dispatch on the step's stream (up to max_launches
  * steps).  f110_profile_end synchronises on the last event and returns the summed
@@ -223,6 +237,22 @@ int f110_profile_end(f110_handle *h, double *scan_ms_total, int32_t *launches);
 int f110_pure_pursuit(f110_handle *h, const double *waypoints, int32_t M, double lookahead, double vgain,
                       double wheelbase, double max_reacquire, const double *state, int32_t n,
                       double *actions, void *stream);
+
+/* The same planner for MANY racelines in one launch, of any length (the reference builds one planner per env from any
+ * CSV, examples/waypoint_follow.py:146-162): waypoints dev [total,3] = the K racelines back to back; offsets [K+1] =
+ * first row of each (offsets[0] = 0, offsets[K] = total) given both as a dev and as a host array; track_of_car dev
+ * [n] int32 = raceline of every car (NULL: all on raceline 0).  workspace: dev doubles,
+ * f110_pure_pursuit_workspace(total, K) of them, holding the bounding boxes of the racelines' 64-segment blocks;
+ * boxes_valid != 0 says the workspace still holds them from an earlier call with the same racelines (skips the small
+ * kernel that fills it).  Racelines are read from global memory (L1 / L2), so there is no length limit.  A raceline
+ * with two equal consecutive waypoints gives (steer 0, speed 4.0) for every car on it, as the reference does (NaN
+ * nearest distance).  f110_pure_pursuit itself stages its raceline in LDS while it fits (gfx950: about 6 400 points)
+ * and otherwise runs this form without a workspace (every block evaluated). */
+int64_t f110_pure_pursuit_workspace(int32_t total_points, int32_t K);
+int f110_pure_pursuit_tracks(f110_handle *h, const double *waypoints, const int32_t *offsets_dev,
+                             const int32_t *offsets_host, int32_t K, const int32_t *track_of_car, double lookahead,
+                             double vgain, double wheelbase, double max_reacquire, const double *state, int32_t n,
+                             double *actions, double *workspace, int32_t boxes_valid, void *stream);
 
 /* ---- function-level entry points (parity tests; all pointers dev) ---- */
 /* ScanSimulator2D.scan(pose, None): n poses [n,3] -> [n,num_beams] (noise off).

@@ -68,7 +68,13 @@ SYMBOLS = {
     'f110_set_scan_stages': [_VP, C.c_char_p],
     'f110_set_step_path': [_VP, _I32, _I32],
     'f110_launch_epoch': [_VP, C.POINTER(C.c_int64)],
+    'f110_graph_create': [_VP, _VP, _I32, C.POINTER(_VP)],
+    'f110_graph_launch': [_VP, _VP],
+    'f110_graph_info': [_VP, C.POINTER(C.c_int32), C.c_char_p],
+    'f110_graph_destroy': [_VP],
     'f110_pure_pursuit': [_VP, _VP, _I32, _D, _D, _D, _D, _VP, _I32, _VP, _VP],
+    'f110_pure_pursuit_workspace': [_I32, _I32],
+    'f110_pure_pursuit_tracks': [_VP, _VP, _VP, _VP, _I32, _VP, _D, _D, _D, _D, _VP, _I32, _VP, _VP, _I32, _VP],
     'f110_profile_begin': [_VP, _I32],
     'f110_profile_end': [_VP, C.POINTER(C.c_double), C.POINTER(C.c_int32)],
     'f110_scan': [_VP, _VP, _I32, _VP, _VP, _VP, _VP],
@@ -116,8 +122,10 @@ def load():
         fn.argtypes = argtypes
         fn.restype = C.c_int
     lib.f110_last_error.restype = C.c_char_p
+    lib.f110_pure_pursuit_workspace.restype = C.c_int64
     lib.f110_destroy.restype = None
     lib.f110_bitmap_destroy.restype = None
+    lib.f110_graph_destroy.restype = None
     _lib = lib
     return lib
 

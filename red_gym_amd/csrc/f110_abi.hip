@@ -47,6 +47,7 @@ struct f110_handle {
     Params agent_params[F110_MAX_AGENTS]; // RaceCar.params per agent index
     Params *d_agent_params = nullptr;
     OppPair *d_opp_pairs = nullptr;   // [N, A-1] opponent ray-cast scratch
+    uint16_t *d_order = nullptr;      // [N, ORDER_STRIDE] per-car chunk order of the car-group path (a hint, see GroupArgs)
     bool has_map = false, bound = false;
     // Bumped whenever a later f110_step would enqueue different kernels or by-value arguments than an earlier one
     // (a table re-allocated, another scan instantiation selected, buffers re-bound): f110_launch_epoch.
@@ -233,6 +234,15 @@ static int upload_beam_cs(f110_handle *h, const double *scan_angles)
 static int upload_agent_params(f110_handle *h);
 static int rebuild_noise_side(f110_handle *h);
 
+// per-car chunk order of the car-group path: starts invalid (= the static order)
+static int alloc_order(f110_handle *h)
+{
+    const size_t n = (size_t)h->cfg.num_envs * h->cfg.num_agents * ORDER_STRIDE;
+    HIP_TRY(hipMalloc((void **)&h->d_order, n * sizeof(uint16_t)));
+    HIP_TRY(hipMemset(h->d_order, 0, n * sizeof(uint16_t)));
+    return F110_OK;
+}
+
 // scratch of the opponent ray cast: allocated here, never in f110_step
 static int alloc_opp_pairs(f110_handle *h)
 {
@@ -295,7 +305,7 @@ extern "C" int f110_create(const f110_config *cfg, f110_handle **out)
     if ((rc = upload_cs(h)) || (rc = rebuild_noise_side(h)) ||
         (rc = upload(&h->d_scan_angles, ang.data(), ang.size())) || (rc = upload_beam_cs(h, ang.data())) ||
         (rc = upload(&h->d_beam_cosines, bcos.data(), bcos.size())) ||
-        (rc = upload(&h->d_side, side.data(), side.size())) || (rc = set_beam_order(h)) || (rc = upload_agent_params(h)) || (rc = alloc_opp_pairs(h))) {
+        (rc = upload(&h->d_side, side.data(), side.size())) || (rc = set_beam_order(h)) || (rc = upload_agent_params(h)) || (rc = alloc_opp_pairs(h)) || (rc = alloc_order(h))) {
         f110_destroy(h);
         return rc;
     }
@@ -308,7 +318,7 @@ extern "C" void f110_destroy(f110_handle *h)
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
     void *ptrs[] = {h->d_cs, h->d_beam_cs, h->d_noise_side, h->d_scan_angles, h->d_beam_cosines, h->d_side,
-                    h->d_chunk0, h->d_agent_params, h->d_opp_pairs, h->d_maps, h->d_env_map};
+                    h->d_chunk0, h->d_agent_params, h->d_opp_pairs, h->d_maps, h->d_env_map, h->d_order};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &sl : h->slots)
@@ -738,6 +748,39 @@ extern "C" int f110_bind(f110_handle *h, const f110_buffers *b)
 }
 
 // ---------------------------------------------------------------- launches
+// Every kernel of the step path goes through emit(): launched at once on a stream (eager, or inside somebody's stream
+// capture), or recorded as a node description for a HIP graph the library builds itself (f110_graph_create).
+struct KernelLaunch {
+    const void *func;
+    dim3 grid, block;
+    unsigned shmem;
+    std::vector<char> args; // the kernel's single by-value argument block
+};
+
+struct Sink {
+    hipStream_t st = nullptr;
+    std::vector<KernelLaunch> *record = nullptr;
+};
+
+template <typename Args>
+static int emit(const Sink &k, const void *func, dim3 grid, dim3 block, unsigned shmem, const Args &a, hipEvent_t ev0 = nullptr,
+                hipEvent_t ev1 = nullptr)
+{
+    static_assert(__is_trivially_copyable(Args), "kernel argument blocks are copied byte for byte");
+    if (k.record) {
+        KernelLaunch l;
+        l.func = func; l.grid = grid; l.block = block; l.shmem = shmem;
+        l.args.assign((const char *)&a, (const char *)&a + sizeof(Args));
+        k.record->push_back(std::move(l));
+        return F110_OK;
+    }
+    void *params[1] = {(void *)&a};
+    // plain launches unless the measurement aid attached events (a captured hipGraph then holds ordinary kernel nodes)
+    if (ev0 || ev1) HIP_TRY(hipExtLaunchKernel(func, grid, block, params, shmem, k.st, ev0, ev1, 0));
+    else HIP_TRY(hipLaunchKernel(func, grid, block, params, shmem, k.st));
+    return F110_OK;
+}
+
 static ScanDev scan_dev(const f110_handle *h)
 {
     ScanDev s;
@@ -749,25 +792,19 @@ static ScanDev scan_dev(const f110_handle *h)
 // ev0 / ev1 (measurement aid, may be null): start / stop events attached to the dispatch itself, which costs
 // less than bracketing the launch with two hipEventRecord calls (those add two barrier packets to the queue)
 template <bool STEP>
-static int launch_scan_t(f110_handle *h, const ScanArgs &a, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr)
+static int launch_scan_t(f110_handle *h, const ScanArgs &a, const Sink &k, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr)
 {
     int waves = 0;
     for (int i = 0; i < a.n_stages; i++) waves += a.stage_cars[i] << a.stage_log2w[i];
     const dim3 grid((waves + SCAN_WAVES - 1) / SCAN_WAVES), block(SCAN_THREADS);
-    // plain launches unless the measurement aid attached events (hipExtLaunchKernelGGL is only needed for those;
-    // a captured hipGraph then holds ordinary kernel nodes)
-#define F110_SCAN_LAUNCH(I, P)                                                                                     \
-    do {                                                                                                           \
-        if (ev0 || ev1) hipExtLaunchKernelGGL((scan_kernel<I, P, STEP>), grid, block, 0, st, ev0, ev1, 0, a);       \
-        else hipLaunchKernelGGL((scan_kernel<I, P, STEP>), grid, block, 0, st, a);                                  \
-    } while (0)
-    if (h->ident && h->pow2) F110_SCAN_LAUNCH(true, true);
-    else if (h->ident) F110_SCAN_LAUNCH(true, false);
-    else if (h->pow2) F110_SCAN_LAUNCH(false, true);
-    else F110_SCAN_LAUNCH(false, false);
-#undef F110_SCAN_LAUNCH
-    HIP_TRY(hipGetLastError());
-    return F110_OK;
+    // sweeps only: F110_SCAN_PAD_LDS=<bytes> of unused dynamic LDS per workgroup caps the workgroups per CU (160 KiB / (8.6 KiB + pad)),
+    // i.e. emulates a lower occupancy without touching the kernel
+    static const unsigned pad_lds = getenv("F110_SCAN_PAD_LDS") ? (unsigned)atoi(getenv("F110_SCAN_PAD_LDS")) : 0u;
+    const void *f = h->ident && h->pow2 ? (const void *)&scan_kernel<true, true, STEP>
+                  : h->ident            ? (const void *)&scan_kernel<true, false, STEP>
+                  : h->pow2             ? (const void *)&scan_kernel<false, true, STEP>
+                                        : (const void *)&scan_kernel<false, false, STEP>;
+    return emit(k, f, grid, block, pad_lds, a, ev0, ev1);
 }
 
 // Waves per car.  Measured on MI355X (profiles/r01g, r01i): a wave's lifetime is bounded
@@ -784,6 +821,25 @@ static int waves_per_car(int n_cars, int num_beams)
     while (wpc > 1 && wpc > nch) wpc /= 2;
     return wpc;
 }
+
+#if defined(F110_TIMELINE)
+// diagnostics build only (tools/timeline.py): per-wave time stamps of the last scan / car-group launch
+static unsigned long long *g_timeline = nullptr;
+static const size_t TIMELINE_WAVES = (size_t)1 << 20;
+static unsigned long long *timeline_buffer()
+{
+    if (!g_timeline && hipMalloc((void **)&g_timeline, TIMELINE_WAVES * 4 * sizeof(unsigned long long)) != hipSuccess) g_timeline = nullptr;
+    if (g_timeline) (void)hipMemset(g_timeline, 0, TIMELINE_WAVES * 4 * sizeof(unsigned long long));
+    return g_timeline;
+}
+extern "C" int f110_debug_timeline(unsigned long long *out_host, int64_t n_waves)
+{
+    if (!g_timeline || !out_host || n_waves < 0 || (size_t)n_waves > TIMELINE_WAVES) return F110_E_INVALID;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out_host, g_timeline, (size_t)n_waves * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return F110_OK;
+}
+#endif
 
 struct StageSpec { int cars, lg; }; // cars < 0: "*", the remaining cars
 
@@ -818,7 +874,7 @@ static bool parse_stage_spec(const char *p, std::vector<StageSpec> &spec, const 
     return true;
 }
 
-static int launch_scan(f110_handle *h, const ScanArgs &a_in, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr)
+static int launch_scan(f110_handle *h, const ScanArgs &a_in, const Sink &st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr)
 {
     ScanArgs a = a_in;
     a.wpc = waves_per_car(a.n_cars, a.scan.nb);
@@ -876,6 +932,9 @@ static int launch_scan(f110_handle *h, const ScanArgs &a_in, hipStream_t st, hip
         if (cars != a.n_cars) return fail(F110_E_INVALID, "scan launch: the stages cover %lld cars, the launch has %d", cars, a.n_cars);
     }
     for (int i = 0; i < 8; i++) { a.stage_cars[i] = i < a.n_stages ? stv[i].cars : 0; a.stage_log2w[i] = i < a.n_stages ? stv[i].lg : 0; }
+#if defined(F110_TIMELINE)
+    a.timeline = timeline_buffer();
+#endif
     return a.state ? launch_scan_t<true>(h, a, st, ev0, ev1) : launch_scan_t<false>(h, a, st, ev0, ev1);
 }
 
@@ -902,33 +961,32 @@ static int group_waves_for(const f110_handle *h, int n_cars)
 }
 
 template <int MODE>
-static int launch_group_t(f110_handle *h, const GroupArgs &a, int waves, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1)
+static int launch_group_t(f110_handle *h, const GroupArgs &a, int waves, const Sink &k, hipEvent_t ev0, hipEvent_t ev1)
 {
     const dim3 grid(a.s.n_cars), block(waves * WAVE);
-#define F110_GROUP_LAUNCH(I, P)                                                                                    \
-    do {                                                                                                           \
-        if (ev0 || ev1) hipExtLaunchKernelGGL((car_group_kernel<I, P, MODE>), grid, block, 0, st, ev0, ev1, 0, a);  \
-        else hipLaunchKernelGGL((car_group_kernel<I, P, MODE>), grid, block, 0, st, a);                             \
-    } while (0)
-    if (h->ident && h->pow2) F110_GROUP_LAUNCH(true, true);
-    else if (h->ident) F110_GROUP_LAUNCH(true, false);
-    else if (h->pow2) F110_GROUP_LAUNCH(false, true);
-    else F110_GROUP_LAUNCH(false, false);
-#undef F110_GROUP_LAUNCH
-    HIP_TRY(hipGetLastError());
-    return F110_OK;
+    const void *f = h->ident && h->pow2 ? (const void *)&car_group_kernel<true, true, MODE>
+                  : h->ident            ? (const void *)&car_group_kernel<true, false, MODE>
+                  : h->pow2             ? (const void *)&car_group_kernel<false, true, MODE>
+                                        : (const void *)&car_group_kernel<false, false, MODE>;
+    return emit(k, f, grid, block, 0, a, ev0, ev1);
 }
 
-static int launch_group(f110_handle *h, const GroupArgs &a, int mode, int waves, hipStream_t st, hipEvent_t ev0 = nullptr,
+static int launch_group(f110_handle *h, const GroupArgs &a, int mode, int waves, const Sink &st, hipEvent_t ev0 = nullptr,
                         hipEvent_t ev1 = nullptr)
 {
     if (a.s.n_cars < 1 || waves < 1 || waves > GROUP_MAX_WAVES) return fail(F110_E_INVALID, "car-group launch: %d cars, %d waves per car", a.s.n_cars, waves);
-    if (mode == 2 && a.s.agents != 1) return fail(F110_E_INVALID, "the fused step needs num_agents == 1");
-    return mode == 2 ? launch_group_t<2>(h, a, waves, st, ev0, ev1)
+    if (mode >= 2 && a.s.agents != 1) return fail(F110_E_INVALID, "the fused step needs num_agents == 1");
+#if defined(F110_TIMELINE)
+    GroupArgs at = a;
+    at.s.timeline = timeline_buffer();
+    return mode == 3 ? launch_group_t<3>(h, at, waves, st, ev0, ev1) : mode == 2 ? launch_group_t<2>(h, at, waves, st, ev0, ev1)
+         : mode == 1 ? launch_group_t<1>(h, at, waves, st, ev0, ev1) : launch_group_t<0>(h, at, waves, st, ev0, ev1);
+#endif
+    return mode == 3 ? launch_group_t<3>(h, a, waves, st, ev0, ev1) : mode == 2 ? launch_group_t<2>(h, a, waves, st, ev0, ev1)
          : mode == 1 ? launch_group_t<1>(h, a, waves, st, ev0, ev1) : launch_group_t<0>(h, a, waves, st, ev0, ev1);
 }
 
-static int run_step(f110_handle *h, const double *actions, int reset_only, hipStream_t st)
+static int run_step(f110_handle *h, const double *actions, int reset_only, const Sink &st)
 {
     const f110_config &c = h->cfg;
     const f110_buffers &b = h->bufs;
@@ -948,8 +1006,21 @@ static int run_step(f110_handle *h, const double *actions, int reset_only, hipSt
         s.in_collision = b.in_collision; s.pending_reset = b.pending_reset; s.reset_only = reset_only;
         s.out_f32 = b.scans; s.out_f64 = b.scans_f64; s.lookups = b.lookups;
     }
-    if (gw && c.num_agents == 1) {
-        // the whole step of every env in ONE launch (car_group_kernel MODE 2)
+    static const bool nofuse = getenv("F110_GROUP_NOFUSE") != nullptr; // sweeps: car groups for the scan only
+    static const bool fuse_dyn = getenv("F110_GROUP_FUSE_DYN") != nullptr; // sweeps: update_pose inside the group kernel, per car
+    if (gw) g.order = h->d_order;
+    if (gw && c.num_agents == 1 && !nofuse) {
+        // one agent: the group kernel also closes the step (env_kernel's work by the last wave of each car); with
+        // fuse_dyn it integrates the car too (MODE 2: the whole step in one launch), else dynamics_kernel runs first
+        if (!fuse_dyn) {
+            DynArgs d;
+            d.n_cars = N; d.agents = c.num_agents; d.state = b.state; d.steer_buf = b.steer_buf; d.steer_cnt = b.steer_cnt;
+            d.noise_step = b.noise_step; d.actions = actions; d.spawn = b.spawn; d.pending_reset = b.pending_reset;
+            d.reset_only = reset_only; d.pose_snap = b.pose_snap; d.in_collision = b.in_collision; d.agent_params = h->d_agent_params;
+            d.time_step = c.timestep; d.integrator = c.integrator;
+            int rc = emit(st, (const void *)&dynamics_kernel, dim3((N + 255) / 256), dim3(256), 0, d);
+            if (rc) return rc;
+        }
         FuseArgs &f = g.f;
         f.state = b.state; f.steer_buf = b.steer_buf; f.steer_cnt = b.steer_cnt; f.noise_step = b.noise_step; f.actions = actions;
         f.spawn = b.spawn; f.pending_reset = b.pending_reset; f.pose_snap = b.pose_snap; f.in_collision = b.in_collision;
@@ -957,7 +1028,7 @@ static int run_step(f110_handle *h, const double *actions, int reset_only, hipSt
         f.collisions = b.collisions; f.collision_idx = b.collision_idx; f.start_rot = b.start_rot; f.near_start = b.near_start;
         f.toggles = b.toggles; f.lap_counts = b.lap_counts; f.lap_times = b.lap_times; f.current_time = b.current_time;
         f.done = b.done; f.checkpoint_done = b.checkpoint_done;
-        int rc = launch_group(h, g, 2, gw, st, ev0, ev1);
+        int rc = launch_group(h, g, fuse_dyn ? 2 : 3, gw, st, ev0, ev1);
         if (rc) return rc;
         if (prof) h->prof_n++;
         return F110_OK;
@@ -967,10 +1038,9 @@ static int run_step(f110_handle *h, const double *actions, int reset_only, hipSt
     d.noise_step = b.noise_step; d.actions = actions; d.spawn = b.spawn; d.pending_reset = b.pending_reset;
     d.reset_only = reset_only; d.pose_snap = b.pose_snap; d.in_collision = b.in_collision; d.agent_params = h->d_agent_params; d.time_step = c.timestep;
     d.integrator = c.integrator;
-    hipLaunchKernelGGL(dynamics_kernel, dim3((N + 255) / 256), dim3(256), 0, st, d);
-    HIP_TRY(hipGetLastError());
+    int rc = emit(st, (const void *)&dynamics_kernel, dim3((N + 255) / 256), dim3(256), 0, d);
+    if (rc) return rc;
 
-    int rc;
     if (gw) rc = launch_group(h, g, 1, gw, st, ev0, ev1);
     else {
         ScanArgs s;
@@ -994,10 +1064,8 @@ static int run_step(f110_handle *h, const double *actions, int reset_only, hipSt
         o.pending_reset = b.pending_reset; o.reset_only = reset_only; o.scans32 = b.scans; o.scans64 = b.scans_f64;
         o.pairs = h->d_opp_pairs;
         const int npairs = N * (c.num_agents - 1);
-        hipLaunchKernelGGL(opp_setup_kernel, dim3((npairs + 127) / 128), dim3(128), 0, st, o);
-        HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(opp_apply_kernel, dim3((N + 3) / 4), dim3(256), 0, st, o);
-        HIP_TRY(hipGetLastError());
+        if ((rc = emit(st, (const void *)&opp_setup_kernel, dim3((npairs + 127) / 128), dim3(128), 0, o))) return rc;
+        if ((rc = emit(st, (const void *)&opp_apply_kernel, dim3((N + 3) / 4), dim3(256), 0, o))) return rc;
     }
 
     EnvArgs e;
@@ -1007,9 +1075,7 @@ static int run_step(f110_handle *h, const double *actions, int reset_only, hipSt
     e.start_rot = b.start_rot; e.near_start = b.near_start; e.toggles = b.toggles; e.lap_counts = b.lap_counts;
     e.lap_times = b.lap_times; e.current_time = b.current_time; e.pending_reset = b.pending_reset; e.done = b.done; e.checkpoint_done = b.checkpoint_done;
     e.time_step = c.timestep; e.car_length = h->params.v[P_LENGTH]; e.car_width = h->params.v[P_WIDTH];
-    hipLaunchKernelGGL(env_kernel, dim3((c.num_envs + 127) / 128), dim3(128), 0, st, e);
-    HIP_TRY(hipGetLastError());
-    return F110_OK;
+    return emit(st, (const void *)&env_kernel, dim3((c.num_envs + 127) / 128), dim3(128), 0, e);
 }
 
 static int check_ready(f110_handle *h, const char *who)
@@ -1041,7 +1107,9 @@ extern "C" int f110_reset(f110_handle *h, const double *poses, const uint8_t *ma
                        c.num_agents, h->bufs.spawn, h->bufs.pending_reset);
     HIP_TRY(hipGetLastError());
     // the zero-action step of F110Env.reset; actions are not read for pending envs
-    return run_step(h, nullptr, 1, st);
+    Sink k;
+    k.st = st;
+    return run_step(h, nullptr, 1, k);
 }
 
 extern "C" int f110_step(f110_handle *h, const double *actions, void *stream)
@@ -1049,7 +1117,105 @@ extern "C" int f110_step(f110_handle *h, const double *actions, void *stream)
     int rc = check_ready(h, "f110_step");
     if (rc) return rc;
     if (!actions) return fail(F110_E_INVALID, "f110_step: null actions");
-    return run_step(h, actions, 0, (hipStream_t)stream);
+    Sink k;
+    k.st = (hipStream_t)stream;
+    return run_step(h, actions, 0, k);
+}
+
+// ---------------------------------------------------------------- the step as a HIP graph built by the library
+struct f110_graph {
+    f110_handle *h = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    hipStream_t cap = nullptr;
+    int64_t epoch = 0;
+    int nodes = 0;
+    std::vector<KernelLaunch> launches; // node argument blocks must outlive hipGraphAddKernelNode only, kept for clarity
+};
+
+extern "C" void f110_graph_destroy(f110_graph *g)
+{
+    if (!g) return;
+    if (g->h) (void)hipSetDevice(g->h->cfg.device);
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    if (g->cap) (void)hipStreamDestroy(g->cap);
+    delete g;
+}
+
+extern "C" int f110_graph_create(f110_handle *h, const double *actions, int32_t how, f110_graph **out)
+{
+    int rc = check_ready(h, "f110_graph_create");
+    if (rc) return rc;
+    if (!actions || !out) return fail(F110_E_INVALID, "f110_graph_create: null argument");
+    if (how != F110_GRAPH_NODES && how != F110_GRAPH_CAPTURE) return fail(F110_E_INVALID, "f110_graph_create: how = %d (0 kernel nodes, 1 stream capture)", how);
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    f110_graph *g = new (std::nothrow) f110_graph;
+    if (!g) return fail(F110_E_INVALID, "f110_graph_create: out of host memory");
+    g->h = h; g->epoch = h->epoch;
+    const bool prof = h->prof_on;
+    h->prof_on = false; // events cannot ride on graph nodes
+    hipError_t e = hipSuccess;
+    if (how == F110_GRAPH_NODES) {
+        Sink k;
+        k.record = &g->launches;
+        rc = run_step(h, actions, 0, k);
+        if (!rc) {
+            e = hipGraphCreate(&g->graph, 0);
+            hipGraphNode_t prev = nullptr;
+            for (size_t i = 0; e == hipSuccess && i < g->launches.size(); i++) {
+                KernelLaunch &l = g->launches[i];
+                void *params[1] = {(void *)l.args.data()};
+                hipKernelNodeParams np;
+                memset(&np, 0, sizeof(np));
+                np.func = const_cast<void *>(l.func); np.gridDim = l.grid; np.blockDim = l.block; np.sharedMemBytes = l.shmem;
+                np.kernelParams = params; np.extra = nullptr;
+                hipGraphNode_t node = nullptr;
+                e = hipGraphAddKernelNode(&node, g->graph, prev ? &prev : nullptr, prev ? 1 : 0, &np); // a chain: each kernel reads what the one before wrote
+                prev = node;
+            }
+            g->nodes = (int)g->launches.size();
+        }
+    } else {
+        e = hipStreamCreateWithFlags(&g->cap, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipStreamBeginCapture(g->cap, hipStreamCaptureModeThreadLocal);
+        if (e == hipSuccess) {
+            Sink k;
+            k.st = g->cap;
+            rc = run_step(h, actions, 0, k);
+            e = hipStreamEndCapture(g->cap, &g->graph);
+            size_t n = 0;
+            if (e == hipSuccess && hipGraphGetNodes(g->graph, nullptr, &n) == hipSuccess) g->nodes = (int)n;
+        }
+    }
+    h->prof_on = prof;
+    if (!rc && e == hipSuccess) e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+    if (rc || e != hipSuccess) {
+        if (!rc) rc = fail(F110_E_HIP, "f110_graph_create: %s", hipGetErrorString(e));
+        f110_graph_destroy(g);
+        return rc;
+    }
+    *out = g;
+    return F110_OK;
+}
+
+extern "C" int f110_graph_launch(f110_graph *g, void *stream)
+{
+    if (!g || !g->exec) return fail(F110_E_INVALID, "f110_graph_launch: null graph");
+    if (g->epoch != g->h->epoch)
+        return fail(F110_E_INVALID, "f110_graph_launch: the graph is stale (a table, map, binding or launch setting of the handle "
+                                    "changed since f110_graph_create: f110_launch_epoch moved from %lld to %lld); create it again",
+                    (long long)g->epoch, (long long)g->h->epoch);
+    HIP_TRY(hipGraphLaunch(g->exec, (hipStream_t)stream));
+    return F110_OK;
+}
+
+extern "C" int f110_graph_info(f110_graph *g, int32_t *nodes, const char *dot_path)
+{
+    if (!g) return fail(F110_E_INVALID, "f110_graph_info: null graph");
+    if (nodes) *nodes = g->nodes;
+    if (dot_path && *dot_path) HIP_TRY(hipGraphDebugDotPrint(g->graph, dot_path, 0));
+    return F110_OK;
 }
 
 extern "C" int f110_set_scan_stages(f110_handle *h, const char *spec)
@@ -1127,6 +1293,39 @@ extern "C" int f110_profile_end(f110_handle *h, double *ms_total, int32_t *launc
 }
 
 // ---------------------------------------------------------------- planner
+// per device: the LDS a workgroup may use (queried once), the dynamic-LDS attribute already granted to
+// pure_pursuit_kernel, and the two-entry raceline header {0, M} of the global-memory fallback of f110_pure_pursuit
+struct DevLds { int max_bytes = -1; size_t pp_attr = 0; int32_t *hdr = nullptr; int hdr_m = -1; };
+static DevLds &device_lds(int dev)
+{
+    static DevLds tab[64];
+    DevLds &d = tab[dev & 63];
+    if (d.max_bytes < 0) {
+        int v = 0;
+        d.max_bytes = hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess ? v : 0;
+        // the attribute may report the 64 KiB every kernel gets without asking; gfx950 grants 160 KiB per workgroup
+        // through hipFuncAttributeMaxDynamicSharedMemorySize
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0)
+            d.max_bytes = std::max(d.max_bytes, 160 * 1024);
+    }
+    return d;
+}
+
+// {0, M} on the device for the single-raceline fallback.  Allocated once per device (not inside a stream capture: a
+// caller that captures a policy with a long raceline makes one eager call first); the 8-byte upload is synchronous.
+static int32_t *single_track_offsets(int dev, int M)
+{
+    DevLds &d = device_lds(dev);
+    if (!d.hdr && hipMalloc((void **)&d.hdr, 2 * sizeof(int32_t)) != hipSuccess) { d.hdr = nullptr; return nullptr; }
+    if (d.hdr_m != M) {
+        const int32_t off[2] = {0, M};
+        if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(d.hdr, off, sizeof(off), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+        d.hdr_m = M;
+    }
+    return d.hdr;
+}
+
 extern "C" int f110_pure_pursuit(f110_handle *h, const double *waypoints, int32_t M, double lookahead, double vgain,
                                  double wheelbase, double max_reacquire, const double *state, int32_t n,
                                  double *actions, void *stream)
@@ -1135,15 +1334,73 @@ extern "C" int f110_pure_pursuit(f110_handle *h, const double *waypoints, int32_
     if (n < 0) return fail(F110_E_INVALID, "f110_pure_pursuit: bad arguments");
     if (n == 0) return F110_OK;
     if (!waypoints || !state || !actions) return fail(F110_E_INVALID, "f110_pure_pursuit: null pointer");
-    if (M < 2 || pure_pursuit_lds_bytes(M) > 156 * 1024)
-        return fail(F110_E_INVALID, "f110_pure_pursuit: M=%d waypoints (2..6400: the raceline is staged in LDS)", M);
+    if (M < 2) return fail(F110_E_INVALID, "f110_pure_pursuit: M=%d waypoints (a raceline has at least 2)", M);
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    const size_t smem = pure_pursuit_lds_bytes(M);
+    const DevLds &dl = device_lds(dev);
+    if (dl.max_bytes <= 0) return fail(F110_E_HIP, "f110_pure_pursuit: cannot query the LDS size of device %d", dev);
+    if (smem + 1024 > (size_t)dl.max_bytes) {
+        // The raceline does not fit the LDS of this device (gfx950: 160 KiB, about 6 400 points): the global-memory
+        // form, without a workspace for block boxes -- every block is evaluated.  f110_pure_pursuit_tracks with a
+        // workspace is the fast way to plan on long or many racelines.
+        PlanTracksArgs t;
+        memset(&t, 0, sizeof(t));
+        int32_t *off = single_track_offsets(dev, M);
+        if (!off) return fail(F110_E_HIP, "f110_pure_pursuit: no device memory for the raceline header");
+        t.t.waypoints = waypoints; t.t.offsets = off; t.t.K = 1; t.t.boxes = nullptr; t.track_of_car = nullptr;
+        t.lookahead = lookahead; t.vgain = vgain; t.wheelbase = wheelbase; t.max_reacquire = max_reacquire;
+        t.state = state; t.n = n; t.actions = actions;
+        hipLaunchKernelGGL(pure_pursuit_tracks_kernel, dim3((n + PPG_WAVES - 1) / PPG_WAVES), dim3(PPG_WAVES * 64), 0, (hipStream_t)stream, t);
+        HIP_TRY(hipGetLastError());
+        return F110_OK;
+    }
     PlanArgs a;
     a.waypoints = waypoints; a.M = M; a.lookahead = lookahead; a.vgain = vgain; a.wheelbase = wheelbase;
     a.max_reacquire = max_reacquire; a.state = state; a.n = n; a.actions = actions;
-    const size_t smem = pure_pursuit_lds_bytes(M);
-    if (smem > 64 * 1024)
+    if (smem > 64 * 1024 && smem > dl.pp_attr) { // raised once per device and size, not on every call (nor inside a captured policy)
         HIP_TRY(hipFuncSetAttribute((const void *)pure_pursuit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        device_lds(dev).pp_attr = smem;
+    }
     hipLaunchKernelGGL(pure_pursuit_kernel, dim3((n + PP_WAVES - 1) / PP_WAVES), dim3(PP_WAVES * 64), smem, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return F110_OK;
+}
+
+extern "C" int64_t f110_pure_pursuit_workspace(int32_t total_points, int32_t K)
+{
+    if (total_points < 0 || K < 0) return 0;
+    return (((int64_t)total_points >> 6) + K) * 5;
+}
+
+extern "C" int f110_pure_pursuit_tracks(f110_handle *h, const double *waypoints, const int32_t *offsets_dev,
+                                        const int32_t *offsets_host, int32_t K, const int32_t *track_of_car, double lookahead,
+                                        double vgain, double wheelbase, double max_reacquire, const double *state, int32_t n,
+                                        double *actions, double *workspace, int32_t boxes_valid, void *stream)
+{
+    (void)h;
+    if (n < 0 || K < 1) return fail(F110_E_INVALID, "f110_pure_pursuit_tracks: bad arguments (n=%d, K=%d)", n, K);
+    if (!waypoints || !offsets_dev || !offsets_host || !workspace) return fail(F110_E_INVALID, "f110_pure_pursuit_tracks: null pointer");
+    int max_m = 0;
+    if (offsets_host[0] != 0) return fail(F110_E_INVALID, "f110_pure_pursuit_tracks: offsets[0] must be 0");
+    for (int k = 0; k < K; k++) {
+        const int64_t m = (int64_t)offsets_host[k + 1] - offsets_host[k];
+        if (m < 2 || m > 0x3fffffff) return fail(F110_E_INVALID, "f110_pure_pursuit_tracks: raceline %d has %lld points (at least 2)", k, (long long)m);
+        max_m = std::max(max_m, (int)m);
+    }
+    TrackSet t;
+    t.waypoints = waypoints; t.offsets = offsets_dev; t.K = K; t.boxes = workspace;
+    if (!boxes_valid) {
+        const int max_blocks = (max_m - 1 + 63) / 64;
+        hipLaunchKernelGGL(track_boxes_kernel, dim3((max_blocks + 3) / 4, K), dim3(256), 0, (hipStream_t)stream, t);
+        HIP_TRY(hipGetLastError());
+    }
+    if (n == 0) return F110_OK;
+    if (!state || !actions) return fail(F110_E_INVALID, "f110_pure_pursuit_tracks: null pointer");
+    PlanTracksArgs a;
+    a.t = t; a.track_of_car = track_of_car; a.lookahead = lookahead; a.vgain = vgain; a.wheelbase = wheelbase;
+    a.max_reacquire = max_reacquire; a.state = state; a.n = n; a.actions = actions;
+    hipLaunchKernelGGL(pure_pursuit_tracks_kernel, dim3((n + PPG_WAVES - 1) / PPG_WAVES), dim3(PPG_WAVES * 64), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return F110_OK;
 }
@@ -1165,9 +1422,13 @@ extern "C" int f110_scan(f110_handle *h, const double *poses, int32_t n, double 
         GroupArgs g;
         memset(&g, 0, sizeof(g));
         g.s = s;
-        return launch_group(h, g, 0, gw, (hipStream_t)stream);
+        Sink k;
+        k.st = (hipStream_t)stream;
+        return launch_group(h, g, 0, gw, k);
     }
-    return launch_scan(h, s, (hipStream_t)stream);
+    Sink k;
+    k.st = (hipStream_t)stream;
+    return launch_scan(h, s, k);
 }
 
 extern "C" int f110_update_pose(f110_handle *h, double *state, double *steer_buf, int32_t *steer_cnt,

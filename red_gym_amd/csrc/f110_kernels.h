@@ -25,6 +25,7 @@ __device__ inline int med3_i32(int x, int lo, int hi)
 __device__ inline unsigned long long vote(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
 constexpr int WAVE = 64;
+constexpr int GROUP_MAX_WAVES_TL = 8; // (diagnostics builds: per-wave stamps of a workgroup)
 #ifndef F110_SCAN_WAVES
 #define F110_SCAN_WAVES 2
 #endif
@@ -237,6 +238,8 @@ struct ScanArgs {
     float *out_f32;              // [N,nb] or NULL
     double *out_f64;             // [N,nb] or NULL
     uint32_t *lookups;           // [N] or NULL (accumulated)
+    unsigned long long *timeline; // diagnostics (builds with -DF110_TIMELINE only, tools/timeline.py): per wave
+                                  // {start, rays started, end} in 100 MHz ticks and (car << 8 | part); else NULL
 };
 
 // One wavefront per car.  Lanes own rays; a finished ray idles (its lookups return 0.0) until at least REFILL_MIN_IDLE lanes are idle, then every idle
@@ -271,6 +274,9 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
 #else
     const ScanArgs *rare = &a; // host pass of the single-source compile: never executed
 #endif
+#if defined(F110_TIMELINE)
+    __shared__ volatile unsigned long long s_tl[GROUP_MAX_WAVES_TL][2]; // stamps wait in LDS, not in registers, for the end of the wave
+#endif
     const int nb = a.scan.nb;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int wid = blockIdx.x * SCAN_WAVES + wave; // wave-uniform (scalar)
@@ -297,6 +303,9 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
         for (int i = threadIdx.x; i < LUT_LDS / 2; i += SCAN_THREADS) dst[i] = src[i];
     }
     for (int i = threadIdx.x; i < ((nb + 63) >> 6); i += SCAN_THREADS) s_chunk0[i] = a.chunk_beam0[i];
+#if defined(F110_TIMELINE)
+    { unsigned long long t = wall_clock64(); asm volatile("" : "+v"(t)); if (lane == 0) s_tl[wave][0] = t; }
+#endif
     __syncthreads();
     MapView mv;
     mv.cells_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(md.cells), 0, (int)md.cells_bytes, 0x00020000);
@@ -348,6 +357,9 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
     // ---- ray march (laser_models.py:107-186) -------------------------------------
     // The first table read of every beam is at the car itself (:129): done once.
     const double d0 = dist_lookup<IDENT, POW2>(mv, s_lut, px, py, true);
+#if defined(F110_TIMELINE)
+    { unsigned long long t = wall_clock64(); asm volatile("" : "+v"(t)); if (lane == 0) s_tl[wave][1] = t; }
+#endif
     unsigned nlook = (unsigned)nbl; // the reference reads the table once per beam before marching
     if (!(d0 > eps && d0 <= max_range)) {
         for (int k = lane; k < nbl; k += WAVE) {
@@ -408,6 +420,9 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
             // ---- march phase: every lane steps (idle lanes are parked by d = 0) until
             // enough lanes are idle again or, once no beams are left, the wave has drained ----
             const int go = next < nbl ? WAVE - REFILL_MIN_IDLE : 0; // keep marching while nact > go
+#if defined(F110_DRAIN_PRIO)
+            if (go == 0) __builtin_amdgcn_s_setprio(F110_DRAIN_PRIO); // experiment: a draining wave ends on its longest ray's dependent chain
+#endif
             do {
                 nlook += (unsigned)nact;
                 const double d = dist_lookup<IDENT, POW2>(mv, s_lut, x, y, active);
@@ -423,6 +438,14 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
     const ScanArgs *ra = rare;
     asm volatile("" : "+s"(ra));
     if (ra->lookups && lane == 0) atomicAdd(&ra->lookups[car], nlook);
+#if defined(F110_TIMELINE)
+    unsigned long long tl_end = wall_clock64();
+    asm volatile("" : "+v"(tl_end));
+    if (ra->timeline && lane == 0) {
+        unsigned long long *tl = ra->timeline + (size_t)wid * 4;
+        tl[0] = s_tl[wave][0]; tl[1] = s_tl[wave][1]; tl[2] = tl_end; tl[3] = ((unsigned long long)car << 8) | (unsigned)part | ((unsigned long long)wpc << 40);
+    }
+#endif
 
     // ---- iTTC result: the flag only; env_kernel zeroes the state (base_classes.py:241-250)
     // once every wave of the car is done.  Plain store: all writers store the same 1.
@@ -477,9 +500,21 @@ struct FuseArgs {               // MODE 2 only: what dynamics_kernel and env_ker
     uint8_t *checkpoint_done;   // [N] or NULL
 };
 
+// Per car, from its previous scan: the order in which its 64-beam chunks are handed out, longest-lived rays first,
+// and how long its longest ray lived.  A hint only -- any permutation of the full chunks gives the same bits -- but
+// it decides when a small launch ends: a launch lasts until its slowest ray is done, the slowest rays (a few hundred
+// dependent lookups creeping along a wall) are the same beams from one step to the next, and a ray that is started at
+// once and not slowed by its SIMD neighbours ends tens of microseconds earlier than one taken late from the queue.
+constexpr int ORDER_STRIDE = MAX_CHUNKS + 2;    // u16 per car: chunk order [MAX_CHUNKS], longest ray age, valid flag
+constexpr int ORDER_AGE = MAX_CHUNKS, ORDER_VALID = MAX_CHUNKS + 1;
+#ifndef F110_GROUP_PRIO_AGE
+#define F110_GROUP_PRIO_AGE 150   // a car whose longest ray lived this many wave iterations last time runs at raised priority
+#endif
+
 struct GroupArgs {
     ScanArgs s;                 // wpc / stage list unused: the grid is one workgroup per car
     FuseArgs f;
+    uint16_t *order;            // [N, ORDER_STRIDE] or NULL (static order, nothing recorded)
 };
 static_assert(__is_trivially_copyable(GroupArgs) && offsetof(GroupArgs, s) == 0 && sizeof(GroupArgs) <= 4096,
               "car_group_kernel re-reads its only argument through the kernarg segment pointer");
@@ -493,21 +528,30 @@ __device__ inline double uniform_f64(double v)
     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
-// MODE 0: ScanSimulator2D.scan(pose, None); 1: the scan of a step (noise, iTTC flag); 2: the whole step (A == 1)
+// MODE 0: ScanSimulator2D.scan(pose, None); 1: the scan of a step (noise, iTTC flag); 2: the whole step (A == 1);
+// 3: scan + env bookkeeping of a step whose dynamics_kernel has run (A == 1)
 template <bool IDENT, bool POW2, int MODE>
-__global__ __launch_bounds__(GROUP_MAX_WAVES * WAVE, 8) void car_group_kernel(GroupArgs a)
+#ifndef F110_GROUP_MIN_WAVES
+#define F110_GROUP_MIN_WAVES 8
+#endif
+__global__ __launch_bounds__(GROUP_MAX_WAVES * WAVE, F110_GROUP_MIN_WAVES) void car_group_kernel(GroupArgs a)
 {
-    constexpr bool STEP = MODE >= 1, FUSED = MODE == 2;
+    constexpr bool STEP = MODE >= 1, FUSED = MODE == 2, CLOSE = MODE >= 2; // CLOSE: the last wave does env_kernel's work
     __shared__ __attribute__((aligned(16))) double s_lut[LUT_LDS];
     __shared__ int s_chunk0[MAX_CHUNKS];
     __shared__ unsigned s_next;     // head of the car's beam queue
     __shared__ unsigned s_arrive;   // waves that have finished their rays (+ 0x10000 per wave with an iTTC hit)
     __shared__ double s_car[12];    // FUSED: new state [7], steer FIFO [2], FIFO count, noise row
     __shared__ double s_rk[FUSED ? 14 : 1]; // FUSED: update_pose_compact's between-stage vectors
+    __shared__ unsigned s_cmax[MAX_CHUNKS]; // longest ray life (wave iterations) seen in each chunk of this scan
 #if defined(__HIP_DEVICE_COMPILE__)
     const GroupArgs *rare = (const GroupArgs *)__builtin_amdgcn_kernarg_segment_ptr();
 #else
     const GroupArgs *rare = &a; // host pass of the single-source compile: never executed
+#endif
+#if defined(F110_TIMELINE)
+    __shared__ volatile unsigned long long s_tl[GROUP_MAX_WAVES_TL][2];
+    __shared__ volatile unsigned s_tlw[GROUP_MAX_WAVES_TL];
 #endif
     const int nb = a.s.scan.nb;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -524,8 +568,19 @@ __global__ __launch_bounds__(GROUP_MAX_WAVES * WAVE, 8) void car_group_kernel(Gr
         double2 *dst = reinterpret_cast<double2 *>(s_lut);
         for (int i = threadIdx.x; i < LUT_LDS / 2; i += nthreads) dst[i] = src[i];
     }
-    for (int i = threadIdx.x; i < ((nb + 63) >> 6); i += nthreads) s_chunk0[i] = a.s.chunk_beam0[i];
+    // chunk order: the car's own from its previous scan, else the static one (long rays along the car's axis first)
+    const bool rec = a.order != nullptr; // (the pointer itself is re-read from the argument block where it is needed)
+    {
+        const uint16_t *order = rec ? a.order + (size_t)car * ORDER_STRIDE : nullptr;
+        const bool own_order = rec && order[ORDER_VALID] != 0;
+        for (int i = threadIdx.x; i < ((nb + 63) >> 6); i += nthreads) s_chunk0[i] = own_order ? order[i] : a.s.chunk_beam0[i];
+        for (int i = threadIdx.x; i < MAX_CHUNKS; i += nthreads) s_cmax[i] = 0;
+        if (own_order && order[ORDER_AGE] >= F110_GROUP_PRIO_AGE) __builtin_amdgcn_s_setprio(2);
+    }
     if (threadIdx.x == 0) { s_next = 0; s_arrive = 0; }
+#if defined(F110_TIMELINE)
+    { unsigned long long t = wall_clock64(); asm volatile("" : "+v"(t)); if (lane == 0) s_tl[wave][0] = t; }
+#endif
     if (FUSED && wave == 0) {
         // RaceCar.update_pose (base_classes.py:254-402) from the OLD state, or RaceCar.reset (:181-202) followed by
         // the zero-action step of F110Env.reset (f110_env.py:335-336): what dynamics_kernel does for this car
@@ -600,6 +655,10 @@ __global__ __launch_bounds__(GROUP_MAX_WAVES * WAVE, 8) void car_group_kernel(Gr
     };
 
     const double d0 = dist_lookup<IDENT, POW2>(mv, s_lut, px, py, true);
+#if defined(F110_TIMELINE)
+    { unsigned long long t = wall_clock64(); asm volatile("" : "+v"(t)); if (lane == 0) { s_tl[wave][1] = t; s_tlw[wave] = 0; } }
+    unsigned tl_wit = 0;
+#endif
     unsigned nlook = 0;
     if (!(d0 > eps && d0 <= max_range)) {
         for (int i = threadIdx.x; i < nb; i += nthreads) {
@@ -616,7 +675,9 @@ __global__ __launch_bounds__(GROUP_MAX_WAVES * WAVE, 8) void car_group_kernel(Gr
 
         bool exhausted = false; // wave-uniform: the car's queue has been handed out
         bool active = false;
-        int beam = -1;
+        int beam = -1;                // the lane's beam in bits 0..11 (num_beams <= 4096) and, above them, the wave
+                                      // iteration at which it was taken (one register for both); -1: none
+        unsigned wit = 0;             // wave iterations so far (scalar)
         double x = px, y = py, c = 0, s = 0, total = 0;
         double nz = 0, sd = 0;
         for (;;) {
@@ -628,6 +689,9 @@ __global__ __launch_bounds__(GROUP_MAX_WAVES * WAVE, 8) void car_group_kernel(Gr
                 if (lane == 0) b0 = atomicAdd(&s_next, (unsigned)nidle);
                 base = __builtin_amdgcn_readfirstlane((int)b0);
                 exhausted = base + nidle >= nb;
+#if defined(F110_TIMELINE)
+                if (exhausted) { unsigned long long t = wall_clock64(); asm volatile("" : "+v"(t)); if (lane == 0) { s_tl[wave][1] = t; s_tlw[wave] = wit; } }
+#endif
             }
             if (!active) {
                 const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32),
@@ -641,7 +705,10 @@ __global__ __launch_bounds__(GROUP_MAX_WAVES * WAVE, 8) void car_group_kernel(Gr
                 const double nzv = nz, sdv = sd;
                 const int ti = beam_theta_index(T0, t0w, b, a.s.scan);
                 const double2 cs = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(a.s.scan.cs) + (size_t)((unsigned)ti * 16u));
-                if (beam >= 0) emit(beam, total, nzv, sdv);
+                // the new beam moves in first (its loads are then dead), the old one is finished from copies: fewer
+                // registers are live in emit()'s rare division path than with the classic order
+                const int done_beam = beam;
+                const double done_total = total;
                 beam = -1;
                 if (take) {
                     c = cs.x;
@@ -649,18 +716,26 @@ __global__ __launch_bounds__(GROUP_MAX_WAVES * WAVE, 8) void car_group_kernel(Gr
                     x = px + d0 * c;
                     y = py + d0 * s;
                     total = d0;
-                    beam = b;
+                    beam = b | (int)(min(wit, 0x7ffffu) << 12);
                     nz = nsv.x;
                     sd = nsv.y;
                     active = true;
+                }
+                if (done_beam >= 0) {
+                    if (rec) atomicMax(&s_cmax[(done_beam & 0xfff) >> 6], wit - ((unsigned)done_beam >> 12)); // (an upper bound of the ray's own iterations)
+                    emit(done_beam & 0xfff, done_total, nzv, sdv);
                 }
             }
             int nact = __popcll(vote(active));
             if (nact == 0) break;
             nlook += (unsigned)min(max(nb - base, 0), nidle); // first read of every beam taken (at the car itself)
             const int go = exhausted ? 0 : WAVE - REFILL_MIN_IDLE;
+#if defined(F110_DRAIN_PRIO)
+            if (go == 0) __builtin_amdgcn_s_setprio(F110_DRAIN_PRIO);
+#endif
             do {
                 nlook += (unsigned)nact;
+                wit++;
                 const double d = dist_lookup<IDENT, POW2>(mv, s_lut, x, y, active);
                 total += d;
                 x += d * c;
@@ -669,39 +744,82 @@ __global__ __launch_bounds__(GROUP_MAX_WAVES * WAVE, 8) void car_group_kernel(Gr
                 active = c1 && c2;
                 nact = __popcll(vote(c1) & vote(c2));
             } while (nact > go);
+#if defined(F110_TIMELINE)
+            tl_wit = wit;
+#endif
         }
     }
     const GroupArgs *ra = rare;
     asm volatile("" : "+s"(ra));
     if (ra->s.lookups && lane == 0 && nlook) atomicAdd(&ra->s.lookups[car], nlook);
-    if (!STEP) return;
-    const bool whit = vote(hit) != 0ull;
-    if (!FUSED) {
+#if defined(F110_TIMELINE)
+    unsigned long long tl_end = wall_clock64();
+    asm volatile("" : "+v"(tl_end));
+    if (ra->s.timeline && lane == 0) {
+        unsigned long long *tl = ra->s.timeline + ((size_t)car * nwaves + wave) * 4;
+        // group form: car | wave << 20 | nwaves << 24 | wave iterations when the queue ran dry << 28 | at the end << 46
+        tl[0] = s_tl[wave][0]; tl[1] = s_tl[wave][1]; tl[2] = tl_end;
+        tl[3] = (unsigned long long)car | ((unsigned long long)wave << 20) | ((unsigned long long)nwaves << 24) |
+                ((unsigned long long)min(s_tlw[wave], 0x3ffffu) << 28) | ((unsigned long long)min(tl_wit, 0x3ffffu) << 46);
+    }
+#endif
+    const bool whit = STEP && vote(hit) != 0ull;
+    if (STEP && !CLOSE) {
         // the flag only; env_kernel zeroes the state.  Plain store: all writers store the same 1.
         if (whit && lane == 0) ra->s.in_collision[car] = 1;
-        return;
     }
-    // ---- FUSED: the last wave of the group to get here closes the car's step (env_kernel for A == 1)
+    if (!CLOSE && !rec) return;
+    // ---- the last wave of the group to get here closes the car's scan: next scan's chunk order, and (CLOSE) the step
     unsigned old = 0;
     if (lane == 0) old = atomicAdd(&s_arrive, 1u | (whit ? 0x10000u : 0u));
     old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
     if ((int)(old & 0xffffu) != nwaves - 1) return;
+    if (rec) {
+        uint16_t *order = ra->order + (size_t)car * ORDER_STRIDE;
+        // rank of every FULL chunk by the longest ray life seen in it (ties: lower chunk first) = its place in the
+        // car's next queue; a trailing partial chunk keeps the last place (slot k -> beam chunk0[k >> 6] + (k & 63))
+        const int nfull = nb >> 6;
+        unsigned mine = 0, amax = 0;
+        int rank = 0;
+        if (lane < nfull) mine = s_cmax[lane];
+        for (int j = 0; j < nfull; j++) {
+            const unsigned v = s_cmax[j];
+            amax = max(amax, v);
+            rank += (lane < nfull && (v > mine || (v == mine && j < lane))) ? 1 : 0;
+        }
+        if (lane < nfull) order[rank] = (uint16_t)(lane << 6);
+        if (lane == 0) {
+            if ((nb & 63) != 0) { order[nfull] = (uint16_t)(nfull << 6); amax = max(amax, s_cmax[nfull]); }
+            order[ORDER_AGE] = (uint16_t)min(amax, 65535u);
+            order[ORDER_VALID] = 1;
+        }
+    }
+    if (!CLOSE) return;
     if (lane != 0) return;
     const bool anyhit = whit || (old >> 16) != 0u;
     const FuseArgs *F = &ra->f;
     double st[7];
+    if (FUSED) {
 #pragma unroll
-    for (int i = 0; i < 7; i++) st[i] = s_car[i];
-    F->pose_snap[(size_t)car * 3] = st[0];       // poses after integration, before iTTC zeroing (base_classes.py:567)
-    F->pose_snap[(size_t)car * 3 + 1] = st[1];
-    F->pose_snap[(size_t)car * 3 + 2] = st[4];
+        for (int i = 0; i < 7; i++) st[i] = s_car[i];
+        F->pose_snap[(size_t)car * 3] = st[0];       // poses after integration, before iTTC zeroing (base_classes.py:567)
+        F->pose_snap[(size_t)car * 3 + 1] = st[1];
+        F->pose_snap[(size_t)car * 3 + 2] = st[4];
+        F->steer_buf[(size_t)car * 2] = s_car[7];
+        F->steer_buf[(size_t)car * 2 + 1] = s_car[8];
+        F->steer_cnt[car] = (int)s_car[9];
+    } else {
+        // MODE 3: dynamics_kernel has written the new state, the FIFO and the pose snapshot, and zeroed noise_step of
+        // a pending env; nobody in this launch but this lane touches the car's state from here on
+#pragma unroll
+        for (int i = 0; i < 7; i++) st[i] = F->state[(size_t)car * 7 + i];
+    }
     if (anyhit) { st[3] = 0.; st[4] = 0.; st[5] = 0.; st[6] = 0.; } // check_ttc, base_classes.py:244-247
+    if (FUSED || anyhit) {
 #pragma unroll
-    for (int i = 0; i < 7; i++) F->state[(size_t)car * 7 + i] = st[i];
-    F->steer_buf[(size_t)car * 2] = s_car[7];
-    F->steer_buf[(size_t)car * 2 + 1] = s_car[8];
-    F->steer_cnt[car] = (int)s_car[9];
-    F->noise_step[car] = (int)s_car[10] + 1;      // one noise row consumed per scan
+        for (int i = 0; i < 7; i++) F->state[(size_t)car * 7 + i] = st[i];
+    }
+    F->noise_step[car] = row + 1;                 // one noise row consumed per scan
     F->in_collision[car] = anyhit ? 1 : 0;
     F->collisions[car] = anyhit ? 1 : 0;          // no other car: Simulator.check_collision finds nothing (:529-543), :581-582
     F->collision_idx[car] = -1;

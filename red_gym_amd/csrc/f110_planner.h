@@ -89,6 +89,9 @@ __global__ __launch_bounds__(PP_WAVES * 64) void pure_pursuit_kernel(PlanArgs a)
     for (int i = threadIdx.x; i < M * 3; i += blockDim.x) s_wp[i] = a.waypoints[i];
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    __shared__ int s_degenerate; // the raceline has a zero-length segment (see below)
+    if (threadIdx.x == 0) s_degenerate = 0;
+    __syncthreads();
     for (int b = wave; b < nblk; b += PP_WAVES) {
         const int i = 64 * b + lane;
         const bool ok = i < nseg;
@@ -96,7 +99,9 @@ __global__ __launch_bounds__(PP_WAVES * 64) void pure_pursuit_kernel(PlanArgs a)
         const double inf = __builtin_inf();
         const double xl = wave_min_f64(ok ? fmin(x0, x1) : inf), xh = wave_max_f64(ok ? fmax(x0, x1) : -inf);
         const double yl = wave_min_f64(ok ? fmin(y0, y1) : inf), yh = wave_max_f64(ok ? fmax(y0, y1) : -inf);
+        const bool deg = ok && ((x1 - x0) * (x1 - x0) + (y1 - y0) * (y1 - y0) == 0.0);
         if (lane == 0) { s_box[4 * b] = xl; s_box[4 * b + 1] = xh; s_box[4 * b + 2] = yl; s_box[4 * b + 3] = yh; }
+        if (__builtin_amdgcn_ballot_w64(deg) != 0ull && lane == 0) s_degenerate = 1;
     }
     __syncthreads();
     __shared__ double s_res[PP_WAVES][4]; // per car of the block: target x, y, speed, 1.0 if there is a target
@@ -162,7 +167,11 @@ __global__ __launch_bounds__(PP_WAVES * 64) void pure_pursuit_kernel(PlanArgs a)
 
     bool have = false;
     double lx = 0, ly = 0, lv = 0;
-    if (best < a.lookahead) {
+    if (s_degenerate) {
+        // Two equal consecutive waypoints: t = 0/0 = NaN on that segment for EVERY pose, np.argmin returns it (the
+        // first NaN), and its NaN distance fails both `<` tests of _get_current_waypoint (:189-204): plan() answers
+        // (4.0, 0.0) whatever the pose.  (fmin-based reductions would drop the NaN and plan as if it were not there.)
+    } else if (best < a.lookahead) {
         // first_point_on_trajectory_intersecting_circle(position, lookahead, wpts, i + t, wrap=True) (:49-129)
         const double targ = (double)best_i + best_t;
         const int start_i = (int)targ;
@@ -221,6 +230,190 @@ __global__ __launch_bounds__(PP_WAVES * 64) void pure_pursuit_kernel(PlanArgs a)
             a.actions[(size_t)c * 2] = steer;
             a.actions[(size_t)c * 2 + 1] = speed;
         }
+    }
+}
+
+// ------------------------------------------------------------------ many tracks / racelines of any length
+// The kernel above stages ONE raceline in LDS (<= 6 400 points).  The reference loads any CSV
+// (examples/waypoint_follow.py:162) and every F110Env has its own planner and track; a shard that drives K random tracks
+// (F110VecEnv.randomize_tracks) therefore needs a raceline PER CAR, and a long raceline must not be refused.  This
+// form reads waypoints and block boxes from global memory (racelines are a few tens of KB: L1 / L2 hits), takes the
+// raceline of every car from a slot table, and walks the block bounds in 64-block words without a register copy of
+// them, so the number of points is unbounded.  Same results as pure_pursuit_kernel (the tests demand `==`).
+struct TrackSet {
+    const double *waypoints;  // [total,3] the K racelines back to back
+    const int32_t *offsets;   // [K+1] first row of raceline k (offsets[K] = total)
+    int K;
+    double *boxes;            // workspace [(total >> 6) + K][5]: xmin, xmax, ymin, ymax of 64-segment block b of raceline k at
+                              // row (offsets[k] >> 6) + k + b; [4] = 1.0 if the block holds a zero-length segment
+};
+
+__device__ inline size_t track_box_row(const TrackSet &t, int k) { return (size_t)(t.offsets[k] >> 6) + (size_t)k; }
+
+// one wave per (raceline, 64-segment block): grid (ceil(max_blocks / 4), K), 256 threads
+__global__ __launch_bounds__(256) void track_boxes_kernel(TrackSet t)
+{
+    const int k = blockIdx.y;
+    const int M = t.offsets[k + 1] - t.offsets[k], nseg = M - 1, nblk = (nseg + 63) >> 6;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= nblk) return;
+    const double *wp = t.waypoints + (size_t)t.offsets[k] * 3;
+    const int i = 64 * b + lane;
+    const bool ok = i < nseg;
+    const double x0 = ok ? wp[3 * i] : 0, y0 = ok ? wp[3 * i + 1] : 0, x1 = ok ? wp[3 * i + 3] : 0, y1 = ok ? wp[3 * i + 4] : 0;
+    const double inf = __builtin_inf();
+    const double xl = wave_min_f64(ok ? fmin(x0, x1) : inf), xh = wave_max_f64(ok ? fmax(x0, x1) : -inf);
+    const double yl = wave_min_f64(ok ? fmin(y0, y1) : inf), yh = wave_max_f64(ok ? fmax(y0, y1) : -inf);
+    const bool degenerate = ok && ((x1 - x0) * (x1 - x0) + (y1 - y0) * (y1 - y0) == 0.0);
+    const bool any_deg = __builtin_amdgcn_ballot_w64(degenerate) != 0ull;
+    if (lane == 0) {
+        double *bx = t.boxes + (track_box_row(t, k) + (size_t)b) * 5;
+        bx[0] = xl; bx[1] = xh; bx[2] = yl; bx[3] = yh; bx[4] = any_deg ? 1.0 : 0.0;
+    }
+}
+
+struct PlanTracksArgs {
+    TrackSet t;
+    const int32_t *track_of_car; // [n] raceline of every car, or NULL (all on raceline 0)
+    double lookahead, vgain, wheelbase, max_reacquire;
+    const double *state;         // [n,7]
+    int n;
+    double *actions;             // [n,2]
+};
+
+constexpr int PPG_WAVES = 4;
+
+__global__ __launch_bounds__(PPG_WAVES * 64) void pure_pursuit_tracks_kernel(PlanTracksArgs a)
+{
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int car = blockIdx.x * PPG_WAVES + wave;
+    if (car >= a.n) return;
+    int k = a.track_of_car ? a.track_of_car[car] : 0;
+    k = __builtin_amdgcn_readfirstlane(k);
+    if (k < 0 || k >= a.t.K) k = 0; // (the host checks the table it is given; a device-side table is the caller's)
+    const int M = a.t.offsets[k + 1] - a.t.offsets[k], nseg = M - 1, nblk = (nseg + 63) >> 6;
+    const double *__restrict__ wp = a.t.waypoints + (size_t)a.t.offsets[k] * 3;
+    // boxes == NULL (f110_pure_pursuit on a raceline too long for LDS, which has no workspace): no pruning, every
+    // block is evaluated -- same results, more work
+    const bool has_box = a.t.boxes != nullptr;
+    const double *__restrict__ box = has_box ? a.t.boxes + track_box_row(a.t, k) * 5 : nullptr;
+    const double px = a.state[(size_t)car * 7], py = a.state[(size_t)car * 7 + 1];
+    bool degenerate = false;
+
+    auto seg_dist = [&](int b, double &t) {
+        const int i = 64 * b + lane;
+        t = 0.0;
+        if (i >= nseg) return __builtin_inf();
+        const double x0 = wp[3 * i], y0 = wp[3 * i + 1];
+        const double dx = wp[3 * i + 3] - x0, dy = wp[3 * i + 4] - y0;
+        const double l2 = dx * dx + dy * dy;
+        if (!has_box && l2 == 0.0) degenerate = true;
+        t = ((px - x0) * dx + (py - y0) * dy) / l2;
+        t = t < 0.0 ? 0.0 : t;
+        t = t > 1.0 ? 1.0 : t;
+        const double qx = px - (x0 + t * dx), qy = py - (y0 + t * dy);
+        return sqrt(qx * qx + qy * qy);
+    };
+    auto box_dist = [&](int b) {
+        if (!has_box) return 0.0;
+        const double ex = fmax(fmax(box[5 * b] - px, px - box[5 * b + 1]), 0.0);
+        const double ey = fmax(fmax(box[5 * b + 2] - py, py - box[5 * b + 3]), 0.0);
+        return sqrt(ex * ex + ey * ey);
+    };
+
+    // nearest_point_on_trajectory (:16-47): pass 1 finds the block whose box is closest (lane j of word w = block
+    // 64 w + j) and an upper bound from its nearest segment; pass 2 evaluates, in index order, the blocks whose box
+    // is within that bound.  The bounds are recomputed per word instead of being kept: any number of blocks.
+    const int nwords = (nblk + 63) >> 6;
+    double lb_best = __builtin_inf();
+    int b_star = 0;
+    for (int w = 0; w < nwords; w++) {
+        const int b = 64 * w + lane;
+        const double lb = b < nblk ? box_dist(b) : __builtin_inf();
+        degenerate = degenerate || (has_box && b < nblk && box[5 * b + 4] != 0.0);
+        const double m = wave_min_f64(lb);
+        if (m < lb_best) { lb_best = m; b_star = 64 * w + (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(lb == m)); }
+    }
+    double t_star;
+    const double d_star = seg_dist(b_star, t_star);
+    const double ub = wave_min_f64(d_star) + 1e-9;
+    double best = __builtin_inf(), best_t = 0;
+    int best_i = 0;
+    for (int w = 0; w < nwords; w++) {
+        const int bl = 64 * w + lane;
+        const double lb = bl < nblk ? box_dist(bl) : __builtin_inf();
+        unsigned long long todo = __builtin_amdgcn_ballot_w64(bl < nblk && !(lb > ub)); // (a NaN pose keeps every block)
+        while (todo) {
+            const int b = 64 * w + (int)__builtin_ctzll(todo);
+            todo &= todo - 1;
+            double t = t_star;
+            const double d = b == b_star ? d_star : seg_dist(b, t);
+            const double m = wave_min_f64(d);
+            if (m < best) {
+                const int l = (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(d == m));
+                best = m; best_i = 64 * b + l; best_t = readlane_f64(t, l);
+            }
+        }
+    }
+
+    degenerate = __builtin_amdgcn_ballot_w64(degenerate) != 0ull; // (without boxes every segment has been looked at by now)
+    bool have = false;
+    double lx = 0, ly = 0, lv = 0;
+    if (degenerate) {
+        // a zero-length segment makes t = 0/0 = NaN there for EVERY pose; the reference's np.argmin returns that
+        // segment, its NaN distance fails both `<` tests (:189-204) and plan() answers (4.0, 0.0)
+    } else if (best < a.lookahead) {
+        const double targ = (double)best_i + best_t;
+        const int start_i = (int)targ;
+        const double start_t = fmod(targ, 1.0);
+        int i2 = 0;
+        bool found = false;
+        for (int base = start_i; base < M - 1 && !found; base += 64) {
+            const int i = base + lane;
+            bool hit = false;
+            double t1, t2;
+            if (i < M - 1 && seg_circle(wp[3 * i], wp[3 * i + 1], wp[3 * i + 3], wp[3 * i + 4], px, py, a.lookahead, t1, t2)) {
+                const bool h1 = t1 >= 0.0 && t1 <= 1.0, h2 = t2 >= 0.0 && t2 <= 1.0;
+                hit = i == start_i ? ((h1 && t1 >= start_t) || (h2 && t2 >= start_t)) : (h1 || h2);
+            }
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+            if (m) { found = true; i2 = base + (int)__builtin_ctzll(m); }
+        }
+        for (int base = -1; base < start_i && !found; base += 64) {
+            const int i = base + lane;
+            bool hit = false;
+            double t1, t2;
+            if (i < start_i) {
+                const int i0 = i < 0 ? i + M : i, i1 = (i + 1) % M;
+                if (seg_circle(wp[3 * i0], wp[3 * i0 + 1], wp[3 * i1], wp[3 * i1 + 1], px, py, a.lookahead, t1, t2))
+                    hit = (t1 >= 0.0 && t1 <= 1.0) || (t2 >= 0.0 && t2 <= 1.0);
+            }
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+            if (m) { found = true; i2 = base + (int)__builtin_ctzll(m); }
+        }
+        if (found) {
+            const int j = i2 < 0 ? i2 + M : i2;
+            have = true; lx = wp[3 * j]; ly = wp[3 * j + 1]; lv = wp[3 * best_i + 2];
+        }
+    } else if (best < a.max_reacquire) {
+        have = true; lx = wp[3 * best_i]; ly = wp[3 * best_i + 1]; lv = wp[3 * best_i + 2];
+    }
+    // get_actuation (:131-144): lane 0 of the car's wave
+    if (lane == 0) {
+        double steer = 0.0, speed = 4.0;
+        if (have) {
+            const double theta = a.state[(size_t)car * 7 + 4];
+            const double wy = sin(-theta) * (lx - px) + cos(-theta) * (ly - py);
+            speed = lv;
+            if (fabs(wy) < 1e-6) steer = 0.;
+            else {
+                const double radius = 1 / (2.0 * wy / (a.lookahead * a.lookahead));
+                steer = atan(a.wheelbase / radius);
+            }
+            speed = a.vgain * speed;
+        }
+        a.actions[(size_t)car * 2] = steer;
+        a.actions[(size_t)car * 2 + 1] = speed;
     }
 }
 

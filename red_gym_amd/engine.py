@@ -344,10 +344,28 @@ class Engine(object):
         if not (torch.is_tensor(waypoints) and waypoints.device == self.device and waypoints.dtype == torch.float64
                 and waypoints.is_contiguous()):
             waypoints = self._dev64(waypoints, (-1, 3))
-        _lib.check(self.lib.f110_pure_pursuit(self._h, _ptr(waypoints), waypoints.shape[0], float(lookahead),
-                                              float(vgain), float(wheelbase), float(max_reacquire), _ptr(st), n,
-                                              _ptr(out), self._stream()))
+        with torch.cuda.device(self.device):  # the launch goes to the CURRENT device's stream table
+            _lib.check(self.lib.f110_pure_pursuit(self._h, _ptr(waypoints), waypoints.shape[0], float(lookahead),
+                                                  float(vgain), float(wheelbase), float(max_reacquire), _ptr(st), n,
+                                                  _ptr(out), self._stream()))
         self._keep_wp = waypoints
+        return out.view(self.B, self.A, 2) if state is None else out
+
+    def pure_pursuit_tracks(self, tracks, track_of_car, lookahead, vgain, wheelbase=0.17145 + 0.15875, max_reacquire=20.,
+                            state=None, out=None):
+        """Pure pursuit when cars drive on different racelines (one launch): `tracks` a TrackSet, `track_of_car` an
+        int32 device tensor [n] (None: raceline 0 for all)."""
+        st = self.t['state'] if state is None else self._dev64(state, (-1, 7))
+        n = st.numel() // 7
+        if out is None:
+            out = torch.empty((n, 2), dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.f110_pure_pursuit_tracks(self._h, _ptr(tracks.waypoints), _ptr(tracks.offsets_dev),
+                                                         _np_ptr(tracks.offsets), tracks.K, _ptr(track_of_car), float(lookahead),
+                                                         float(vgain), float(wheelbase), float(max_reacquire), _ptr(st), n, _ptr(out),
+                                                         _ptr(tracks.workspace), int(tracks.boxes_valid), self._stream()))
+        tracks.boxes_valid = True
+        self._keep_tracks = (tracks, track_of_car)
         return out.view(self.B, self.A, 2) if state is None else out
 
     def set_scan_stages(self, spec=None):
@@ -389,6 +407,28 @@ class Engine(object):
             pass
 
 
+class TrackSet(object):
+    """K racelines [M_k,3] = (x, y, speed) packed for f110_pure_pursuit_tracks: waypoints back to back on the device,
+    their row offsets (device + host), and the workspace of block bounding boxes (filled by the first call)."""
+
+    def __init__(self, racelines, device):
+        lib = _lib.load()
+        arrs = []
+        for w in racelines:
+            w = w.detach().cpu().numpy() if torch.is_tensor(w) else np.asarray(w)
+            arrs.append(np.ascontiguousarray(w, dtype=np.float64).reshape(-1, 3))
+        if not arrs:
+            raise ValueError('TrackSet needs at least one raceline')
+        self.K = len(arrs)
+        self.offsets = np.ascontiguousarray(np.concatenate([[0], np.cumsum([a.shape[0] for a in arrs])]), dtype=np.int32)
+        self.device = torch.device(device)
+        self.waypoints = torch.as_tensor(np.concatenate(arrs, axis=0), device=self.device)
+        self.offsets_dev = torch.as_tensor(self.offsets, device=self.device)
+        n_ws = int(lib.f110_pure_pursuit_workspace(int(self.offsets[-1]), self.K))
+        self.workspace = torch.zeros((max(n_ws, 1),), dtype=torch.float64, device=self.device)
+        self.boxes_valid = False
+
+
 def edt_squared(free_mask):
     """Host exact squared EDT (the integer kernel of f110_set_map_occupancy)."""
     lib = _lib.load()
@@ -414,8 +454,9 @@ def check_done(poses, start_poses, start_rot, current_time, collisions, near_sta
     lap_counts = torch.empty((n, A), dtype=torch.int32, device=dev)
     done = torch.empty((n,), dtype=torch.bool, device=dev)
     ckpt = torch.empty((n, A), dtype=torch.bool, device=dev)
-    _lib.check(lib.f110_check_done(None, _ptr(poses), _ptr(start_poses), _ptr(start_rot), _ptr(current_time),
-                                   _ptr(collisions), n, A, int(ego_idx), _ptr(near_start), _ptr(toggles),
-                                   _ptr(lap_counts), _ptr(lap_times), _ptr(done), _ptr(ckpt),
-                                   C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    with torch.cuda.device(dev):  # a NULL handle launches on the calling thread's current device
+        _lib.check(lib.f110_check_done(None, _ptr(poses), _ptr(start_poses), _ptr(start_rot), _ptr(current_time),
+                                       _ptr(collisions), n, A, int(ego_idx), _ptr(near_start), _ptr(toggles),
+                                       _ptr(lap_counts), _ptr(lap_times), _ptr(done), _ptr(ckpt),
+                                       C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
     return lap_counts, done, ckpt

@@ -29,10 +29,11 @@ class PurePursuitPlanner(object):
     def plan(self, pose_x, pose_y, pose_theta, lookahead_distance, vgain):
         self._pose[0], self._pose[1], self._pose[2] = float(pose_x), float(pose_y), float(pose_theta)
         self._state[0, self._idx] = self._pose.to(self.device, non_blocking=True)
-        st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        _lib.check(self.lib.f110_pure_pursuit(None, C.c_void_p(self._wp.data_ptr()), self._wp.shape[0],
-                                              float(lookahead_distance), float(vgain), float(self.wheelbase),
-                                              float(self.max_reacquire), C.c_void_p(self._state.data_ptr()), 1,
-                                              C.c_void_p(self._act.data_ptr()), st))
+        with torch.cuda.device(self.device):  # h = NULL: the kernel goes to the current device, which must be ours
+            st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            _lib.check(self.lib.f110_pure_pursuit(None, C.c_void_p(self._wp.data_ptr()), self._wp.shape[0],
+                                                  float(lookahead_distance), float(vgain), float(self.wheelbase),
+                                                  float(self.max_reacquire), C.c_void_p(self._state.data_ptr()), 1,
+                                                  C.c_void_p(self._act.data_ptr()), st))
         steer, speed = self._act[0].tolist()  # one device -> host hop per plan (the reference plans on the host)
         return speed, steer

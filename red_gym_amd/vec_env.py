@@ -122,6 +122,10 @@ class F110VecEnv(object):
         self.eng._grow_noise_if_needed()
         # `copies` > 1 captures that many identical graphs, replayed in turn (an experiment: two alternating execs
         # replay no faster than one, profiles/r02_graph_vs_eager.txt)
+        if getattr(self, '_graphs', None):
+            # a replay of the graphs being dropped may still be in flight (f110_set_scan_stages bumps the epoch without
+            # synchronising): a graph exec must outlive its last launch
+            torch.cuda.current_stream(self.device).synchronize()
         self._graphs, self._g_next = [], 0
         for _ in range(max(1, int(copies))):
             side = torch.cuda.Stream(device=self.device)
@@ -156,6 +160,47 @@ class F110VecEnv(object):
         self.eng.host_steps_bound += 1
         return self._result()
 
+    # ------------------------------------------------------------------ hipGraph built by the library
+    def build_step_graph(self, how='nodes'):
+        """The step as a HIP graph built by the library itself (f110_graph_create: 'nodes' = explicit kernel nodes,
+        'capture' = a capture on a private non-blocking stream) instead of a torch capture.  Returns the static action
+        buffer [B,A,2]; `step_lib_graph()` replays."""
+        import ctypes as C
+        from . import _lib
+        if getattr(self, '_g_actions', None) is None:
+            self._g_actions = torch.zeros((self.num_envs, self.num_agents, 2), dtype=torch.float64, device=self.device)
+        self._drop_lib_graph()
+        self.eng._grow_noise_if_needed()
+        g = C.c_void_p()
+        _lib.check(self.eng.lib.f110_graph_create(self.eng._h, C.c_void_p(self._g_actions.data_ptr()),
+                                                  {'nodes': 0, 'capture': 1}[how], C.byref(g)))
+        self._lg, self._lg_how, self._lg_epoch = g, how, self.eng.launch_epoch()
+        return self._g_actions
+
+    def _drop_lib_graph(self):
+        if getattr(self, '_lg', None):
+            torch.cuda.current_stream(self.device).synchronize()  # a graph exec must outlive its last launch
+            self.eng.lib.f110_graph_destroy(self._lg)
+            self._lg = None
+
+    def lib_graph_info(self, dot_path=None):
+        import ctypes as C
+        from . import _lib
+        n = C.c_int32(0)
+        _lib.check(self.eng.lib.f110_graph_info(self._lg, C.byref(n), dot_path.encode() if dot_path else None))
+        return n.value
+
+    def step_lib_graph(self, actions=None):
+        from . import _lib
+        if actions is not None:
+            self._g_actions.copy_(self._as_dev(actions, 2))
+        self.eng._grow_noise_if_needed()
+        if self.eng.launch_epoch() != self._lg_epoch:
+            self.build_step_graph(self._lg_how)
+        _lib.check(self.eng.lib.f110_graph_launch(self._lg, self.eng._stream()))
+        self.eng.host_steps_bound += 1
+        return self._result()
+
     def pure_pursuit(self, waypoints, lookahead, vgain, wheelbase=0.17145 + 0.15875):
         """Batched pure-pursuit actions for the current poses (examples/waypoint_follow.py planner
         on the GPU); waypoints [M,3] = (x, y, speed)."""
@@ -163,21 +208,33 @@ class F110VecEnv(object):
             waypoints = torch.as_tensor(np.ascontiguousarray(waypoints, dtype=np.float64), device=self.device)
         return self.eng.pure_pursuit(waypoints, lookahead, vgain, wheelbase)
 
+    def raceline_slots(self, waypoint_sets, assign):
+        """Packs K racelines [M_k,3] = (x, y, speed) and the raceline of every env (int array [num_envs], e.g. the map
+        slots of randomize_tracks) for pure_pursuit_tracks: the planner's counterpart of f110_assign_maps.  Returns
+        (TrackSet, int32 device tensor [num_envs * num_agents])."""
+        from .engine import TrackSet
+        assign = np.asarray(assign)
+        if assign.shape != (self.num_envs,) or assign.min() < 0 or assign.max() >= len(waypoint_sets):
+            raise ValueError('assign must hold one raceline index (0..%d) per env' % (len(waypoint_sets) - 1))
+        ts = TrackSet(waypoint_sets, self.device)
+        of_car = torch.as_tensor(np.repeat(assign.astype(np.int32), self.num_agents), device=self.device)
+        return ts, of_car
+
+    def pure_pursuit_tracks(self, tracks, track_of_car, lookahead, vgain, wheelbase=0.17145 + 0.15875):
+        """Pure-pursuit actions [B,A,2] when every env has its own raceline (raceline_slots): ONE planner launch for
+        all tracks, racelines of any length, capturable in a hipGraph together with the step."""
+        return self.eng.pure_pursuit_tracks(tracks, track_of_car, lookahead, vgain, wheelbase)
+
     def pure_pursuit_blocks(self, waypoint_sets, assign, lookahead, vgain, wheelbase=0.17145 + 0.15875):
         """Pure-pursuit actions when blocks of envs drive on different tracks (randomize_tracks): waypoint_sets[k]
-        is the raceline [M_k,3] = (x, y, speed) of slot k, assign the int array [num_envs] of slots (blocks of
-        consecutive envs).  One planner launch per block, all into one [B,A,2] action tensor."""
-        if getattr(self, '_pp_actions', None) is None:
-            self._pp_actions = torch.empty((self.num_envs, self.num_agents, 2), dtype=torch.float64, device=self.device)
-        assign = np.asarray(assign)
-        bounds = np.flatnonzero(np.diff(assign)) + 1
-        for lo, hi in zip(np.r_[0, bounds], np.r_[bounds, self.num_envs]):
-            wp = waypoint_sets[int(assign[lo])]
-            if not torch.is_tensor(wp) or wp.device != self.device:
-                wp = torch.as_tensor(np.ascontiguousarray(wp, dtype=np.float64), device=self.device)
-            self.eng.pure_pursuit(wp, lookahead, vgain, wheelbase, state=self.eng.t['state'][lo:hi],
-                                  out=self._pp_actions[lo:hi].view(-1, 2))
-        return self._pp_actions
+        is the raceline [M_k,3] = (x, y, speed) of slot k, assign the int array [num_envs] of slots.  One planner
+        launch for all of them (the packed racelines are cached while the same objects are passed)."""
+        key = (id(waypoint_sets), len(waypoint_sets), np.asarray(assign).tobytes())
+        if getattr(self, '_pp_tracks_key', None) != key:
+            self._pp_tracks = self.raceline_slots(waypoint_sets, assign)
+            self._pp_tracks_key = key
+        ts, of_car = self._pp_tracks
+        return self.eng.pure_pursuit_tracks(ts, of_car, lookahead, vgain, wheelbase)
 
     def update_params(self, params, index=-1):
         """base_classes.py:507-527: index < 0 updates every agent, otherwise agent `index` of
@@ -223,4 +280,5 @@ class F110VecEnv(object):
         return self.eng.t['state']
 
     def close(self):
+        self._drop_lib_graph()
         self.eng.close()

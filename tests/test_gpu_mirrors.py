@@ -187,11 +187,125 @@ def test_lidar_dataset_writer_reference_format(golden, assets, tmp_path):
     env.close()
 
 
-@pytest.mark.parametrize('M', [2, 3, 64, 65, 66, 130, 783, 4097, 5000, 6400])
+def _example_raceline(assets):
+    from argparse import Namespace
+    import yaml
+    conf = Namespace(**yaml.safe_load(open(os.path.join(assets, 'config_example_map.yaml'))))
+    w = np.loadtxt(os.path.join(assets, 'example_waypoints.csv'), delimiter=conf.wpt_delim, skiprows=conf.wpt_rowskip)
+    return np.ascontiguousarray(w[:, [conf.wpt_xind, conf.wpt_yind, conf.wpt_vind]])
+
+
+def _hip_plan(wp, poses, lookahead, vgain, wheelbase=0.17145 + 0.15875):
+    """f110_pure_pursuit on poses [n,3] = (x, y, theta) -> actions [n,2] = (steer, speed)"""
+    import ctypes as C
+    import torch
+    from red_gym_amd.engine import _lib, _ptr
+    dev = torch.device('cuda', 0)
+    st = np.zeros((len(poses), 7))
+    st[:, [0, 1, 4]] = poses
+    st = torch.as_tensor(st, device=dev)
+    w = torch.as_tensor(np.ascontiguousarray(wp, dtype=np.float64), device=dev)
+    out = torch.empty((len(poses), 2), dtype=torch.float64, device=dev)
+    _lib.check(_lib.load().f110_pure_pursuit(None, _ptr(w), w.shape[0], float(lookahead), float(vgain), float(wheelbase), 20.0,
+                                             _ptr(st), len(poses), _ptr(out), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    return out.cpu().numpy()
+
+
+def test_hip_pure_pursuit_reproduces_reference_recorded_actions(golden, assets):
+    """ONE hop from the kernel to the reference: the poses the reference's own PurePursuitPlanner
+    (examples/waypoint_follow.py:183-217) saw in its closed loops -- g8: 1 agent, 3 329 steps; g9: 2 agents with their
+    own vgain, 3 509 steps -- go through f110_pure_pursuit and must give the actions it recorded: the speed `==` (a
+    table value times vgain), the steering angle to 1e-9 (trigonometry of the actuation)."""
+    wp = _example_raceline(assets)
+    tlad = 0.82461887897713965
+    g = golden('g8_env.npz')
+    poses = np.concatenate([g['reset_obs'][None, :3], np.stack([g['x'], g['y'], g['theta']], axis=1)[:-1]])
+    act = _hip_plan(wp, poses, tlad, 1.375)
+    assert np.array_equal(act[:, 1], g['actions'][:, 1])
+    assert np.abs(act[:, 0] - g['actions'][:, 0]).max() < 1e-9
+    g = golden('g9_env2.npz')
+    for a in range(2):
+        poses = np.concatenate([g['reset_obs'][a][None], np.stack([g['x'][:, a], g['y'][:, a], g['theta'][:, a]], axis=1)[:-1]])
+        act = _hip_plan(wp, poses, tlad, g['vgains'][a])
+        assert np.array_equal(act[:, 1], g['actions'][:, a, 1]), a
+        assert np.abs(act[:, 0] - g['actions'][:, a, 0]).max() < 1e-9, a
+
+
+def test_hip_pure_pursuit_degenerate_raceline(assets):
+    """Two equal consecutive waypoints: the reference's nearest-point search divides 0 by 0 on that segment, np.argmin
+    returns it, and the NaN distance makes plan() answer (4.0, 0.0) for every pose (waypoint_follow.py:16-47, :189-212).
+    Both planner kernels (LDS, global memory) and the checker do the same."""
+    import torch
+    from oracle.planner import PurePursuitPlanner, Raceline
+    from red_gym_amd.engine import TrackSet, _lib, _ptr
+    import ctypes as C
+    wp = _example_raceline(assets)
+    bad = np.concatenate([wp[:200], wp[199:200], wp[200:]])
+    poses = np.stack([wp[::50, 0], wp[::50, 1], np.zeros(len(wp[::50]))], axis=1)
+    pl = PurePursuitPlanner.__new__(PurePursuitPlanner)
+    pl.wheelbase, pl.max_reacquire, pl.line, pl.speeds = 0.33, 20., Raceline(bad[:, :2]), bad[:, 2]
+    with np.errstate(all='ignore'):
+        assert pl.plan(poses[3, 0], poses[3, 1], 0.3, 0.9, 1.2) == (4.0, 0.0)
+    act = _hip_plan(bad, poses, 0.9, 1.2)
+    assert np.array_equal(act, np.tile([0.0, 4.0], (len(poses), 1)))
+    assert not np.array_equal(_hip_plan(wp, poses, 0.9, 1.2), act)
+    # global-memory form: raceline 0 sound, raceline 1 degenerate
+    dev = torch.device('cuda', 0)
+    ts = TrackSet([wp, bad], dev)
+    st = np.zeros((2 * len(poses), 7)); st[:, [0, 1, 4]] = np.concatenate([poses, poses])
+    st = torch.as_tensor(st, device=dev)
+    of_car = torch.as_tensor(np.repeat([0, 1], len(poses)).astype(np.int32), device=dev)
+    out = torch.empty((2 * len(poses), 2), dtype=torch.float64, device=dev)
+    _lib.check(_lib.load().f110_pure_pursuit_tracks(None, _ptr(ts.waypoints), _ptr(ts.offsets_dev), ts.offsets.ctypes.data_as(C.c_void_p),
+                                                    2, _ptr(of_car), 0.9, 1.2, 0.17145 + 0.15875, 20.0, _ptr(st), 2 * len(poses), _ptr(out),
+                                                    _ptr(ts.workspace), 0, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    got = out.cpu().numpy()
+    assert np.array_equal(got[:len(poses)], _hip_plan(wp, poses, 0.9, 1.2)) and np.array_equal(got[len(poses):], act)
+
+
+def test_hip_pure_pursuit_many_tracks_one_launch(assets):
+    """f110_pure_pursuit_tracks: K racelines of different lengths (one beyond the LDS kernel's reach), every car on its
+    own, in ONE launch `==` K single-raceline calls of f110_pure_pursuit; a second call re-uses the block boxes."""
+    import torch
+    from red_gym_amd import F110VecEnv, workload
+    rng = np.random.default_rng(11)
+    wp = _example_raceline(assets)
+    lines = [wp, wp[::-1].copy(), wp[100:400].copy()]
+    th = np.linspace(0, 2 * np.pi, 9000, endpoint=False)
+    lines.append(np.stack([40 * np.cos(th) * (1 + 0.1 * np.sin(5 * th)), 25 * np.sin(th), rng.uniform(2, 8, 9000)], axis=1))
+    B = 192
+    env = F110VecEnv(B, map=workload.EXAMPLE_MAP, num_agents=1, autoreset=False)
+    assign = rng.integers(0, len(lines), B)          # any mixture: no blocks of envs needed
+    poses = np.zeros((B, 1, 3))
+    for b in range(B):
+        ln = lines[assign[b]]
+        k = rng.integers(0, len(ln))
+        poses[b, 0] = [ln[k, 0] + rng.normal(0, 0.3), ln[k, 1] + rng.normal(0, 0.3), rng.uniform(-3, 3)]
+    poses[:8, 0, :2] += 5.0
+    env.reset(poses)
+    ts, of_car = env.raceline_slots(lines, assign)
+    act = env.pure_pursuit_tracks(ts, of_car, 0.9, 1.2).cpu().numpy()
+    assert ts.boxes_valid
+    act2 = env.pure_pursuit_tracks(ts, of_car, 0.9, 1.2).cpu().numpy()   # boxes re-used
+    assert np.array_equal(act, act2)
+    st = env.state.cpu().numpy()[:, 0]
+    for k, ln in enumerate(lines):
+        m = assign == k
+        ref = _hip_plan(ln, st[m][:, [0, 1, 4]], 0.9, 1.2)
+        assert np.array_equal(act[m, 0], ref), k
+    # the cached convenience form used by examples/random_tracks.py
+    act3 = env.pure_pursuit_blocks(lines, assign, 0.9, 1.2).cpu().numpy()
+    assert np.array_equal(act3, act)
+    env.close()
+
+
+@pytest.mark.parametrize('M', [2, 3, 64, 65, 66, 130, 783, 4097, 5000, 6400, 6401, 8192, 20000])
 def test_hip_pure_pursuit_raceline_lengths(M):
     """The planner kernel works through the raceline in 64-segment blocks (one wavefront per car, blocks skipped by
     their bounding box, a second mask word beyond 64 blocks): racelines of 2 ... 6400 points -- block boundaries, the
-    >64-block path, the >64 KiB LDS path -- against the NumPy checker on poses on, near, off and far from the line."""
+    >64-block path, the >64 KiB LDS path -- and beyond what LDS holds (6401 ... 20000 points: the global-memory form
+    inside f110_pure_pursuit, every block evaluated) against the NumPy checker on poses on, near, off and far from
+    the line; for the long ones also f110_pure_pursuit_tracks with its block boxes (`==` the former)."""
     import torch
     from argparse import Namespace
     from oracle.planner import PurePursuitPlanner, Raceline
@@ -227,3 +341,11 @@ def test_hip_pure_pursuit_raceline_lengths(M):
         assert abs(got[i, 0] - stg) < 1e-12 and abs(got[i, 1] - sp) < 1e-12, (M, i, got[i], (stg, sp))
     with pytest.raises(ValueError):
         _lib.check(lib.f110_pure_pursuit(None, _ptr(wp), 1, lookahead, 1.2, 0.33, 20.0, _ptr(st), n, _ptr(out), None))
+    if M >= 4097:
+        from red_gym_amd.engine import TrackSet
+        ts = TrackSet([np.column_stack([xy, v])], dev)
+        out2 = torch.empty((n, 2), dtype=torch.float64, device=dev)
+        _lib.check(lib.f110_pure_pursuit_tracks(None, _ptr(ts.waypoints), _ptr(ts.offsets_dev), ts.offsets.ctypes.data_as(C.c_void_p), 1,
+                                                None, lookahead, 1.2, 0.33, 20.0, _ptr(st), n, _ptr(out2), _ptr(ts.workspace), 0,
+                                                C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        assert np.array_equal(out2.cpu().numpy(), got)

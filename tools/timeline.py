@@ -1,0 +1,80 @@
+"""Per-wave timeline of ONE step's scan / car-group launch (diagnostics build of the library):
+    hipcc ... -DF110_TIMELINE -o build_variants/timeline.so ; F110_LIB=build_variants/timeline.so python tools/timeline.py
+    [--envs B] [--path classic|group:W] [--stages SPEC] [--nofuse]
+Prints, in microseconds from the first wave's start: when waves start (percentiles), wave lifetimes by kind (whole
+car / part of a car), the end of the launch, and how many waves are resident over time."""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch  # noqa: E402
+from red_gym_amd import F110VecEnv, _lib, workload  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--envs', type=int, default=4096)
+ap.add_argument('--path', default='classic')
+ap.add_argument('--stages', default='')
+ap.add_argument('--warm', type=int, default=60)
+a = ap.parse_args()
+lib = _lib.load()
+lib.f110_debug_timeline.argtypes = [C.c_void_p, C.c_int64]
+B = a.envs
+env = F110VecEnv(B, map=workload.EXAMPLE_MAP, num_agents=1, autoreset=True)
+name, _, w = a.path.partition(':')
+env.eng.set_step_path(name, int(w or 0))
+if a.stages:
+    env.eng.set_scan_stages(a.stages)
+env.reset(torch.as_tensor(workload.spawn_poses(B, 1), device=env.device))
+acts = torch.as_tensor(workload.action_pool(8, B, 1), device=env.device)
+for k in range(a.warm):
+    env.step(acts[k % 8])
+torch.cuda.synchronize()
+env.step(acts[0])
+torch.cuda.synchronize()
+N = 1 << 18
+buf = np.zeros((N, 4), dtype=np.uint64)
+assert lib.f110_debug_timeline(buf.ctypes.data_as(C.c_void_p), N) == 0
+buf = buf[buf[:, 0] != 0]
+t0 = buf[:, 0].min()
+start = (buf[:, 0] - t0).astype(np.float64) / 100.0   # 100 MHz ticks -> us
+ready = (buf[:, 1] - t0).astype(np.float64) / 100.0
+end = (buf[:, 2] - t0).astype(np.float64) / 100.0
+group = name == 'group'
+if group:  # car | wave << 20 | nwaves << 24 | iterations when the queue ran dry << 28 | iterations at the end << 46
+    car = (buf[:, 3] & np.uint64(0xfffff)).astype(np.int64)
+    wpc = ((buf[:, 3] >> np.uint64(24)) & np.uint64(0xf)).astype(np.int64)
+    it_dry = ((buf[:, 3] >> np.uint64(28)) & np.uint64(0x3ffff)).astype(np.int64)
+    it_end = ((buf[:, 3] >> np.uint64(46)) & np.uint64(0x3ffff)).astype(np.int64)
+else:
+    wpc = (buf[:, 3] >> np.uint64(40)).astype(np.int64)
+    car = ((buf[:, 3] >> np.uint64(8)) & np.uint64(0xffffffff)).astype(np.int64)
+print('%s %s stages=%r: %d waves, launch ends at %.1f us after the first wave starts' % (B, a.path, a.stages, len(buf), end.max()))
+pc = lambda x: ' '.join('%.1f' % v for v in np.percentile(x, [0, 10, 50, 90, 99, 100]))  # noqa: E731
+print('  wave start      p0/10/50/90/99/100: ' + pc(start))
+print('  prologue (start -> first rays)     : ' + pc(ready - start))
+for k in sorted(set(wpc.tolist())):
+    m = wpc == k
+    print('  %d wave(s)/car: %6d waves, lifetime %s   end %s' % (k, m.sum(), pc((end - start)[m]), pc(end[m])))
+# per car: end of its last wave
+last = {}
+for c, e in zip(car.tolist(), end.tolist()):
+    last[c] = max(last.get(c, 0.0), e)
+ce = np.array(list(last.values()))
+print('  car completion  p0/10/50/90/99/100: ' + pc(ce))
+if group:
+    # the drain phase of a wave (queue dry -> last ray done): microseconds per wave iteration, for the waves that end last
+    # (nearly alone on the chip) and for all
+    drain_us, drain_it = end - ready, it_end - it_dry
+    ok = drain_it > 20
+    last = np.argsort(end)[-12:]
+    print('  wave iterations per wave: ' + pc(it_end) + '   of them after the queue ran dry: ' + pc(drain_it))
+    print('  us per iteration in the drain phase, all waves: ' + ' '.join('%.3f' % v for v in np.percentile((drain_us / np.maximum(drain_it, 1))[ok], [10, 50, 90])))
+    print('  the 12 waves that end last: ' + '  '.join('end %.0f us: %d it, drain %d it @ %.3f us' % (end[i], it_end[i], drain_it[i], drain_us[i] / max(drain_it[i], 1)) for i in last))
+grid = np.arange(0.0, end.max() + 5.0, 5.0)
+res = [(int(((start <= t) & (end > t)).sum())) for t in grid]
+print('  resident waves every 5 us: ' + ' '.join(str(r) for r in res))
+env.close()
