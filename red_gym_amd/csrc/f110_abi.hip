@@ -47,6 +47,7 @@ struct f110_handle {
     Params agent_params[F110_MAX_AGENTS]; // RaceCar.params per agent index
     Params *d_agent_params = nullptr;
     OppPair *d_opp_pairs = nullptr;   // [N, A-1] opponent ray-cast scratch
+    uint32_t *d_arrive = nullptr;     // [N] arrival counters of the closing scan_kernel (zero between launches)
     uint16_t *d_order = nullptr;      // [N, ORDER_STRIDE] per-car chunk order of the car-group path (a hint, see GroupArgs)
     bool has_map = false, bound = false;
     // Bumped whenever a later f110_step would enqueue different kernels or by-value arguments than an earlier one
@@ -240,6 +241,9 @@ static int alloc_order(f110_handle *h)
     const size_t n = (size_t)h->cfg.num_envs * h->cfg.num_agents * ORDER_STRIDE;
     HIP_TRY(hipMalloc((void **)&h->d_order, n * sizeof(uint16_t)));
     HIP_TRY(hipMemset(h->d_order, 0, n * sizeof(uint16_t)));
+    const size_t cars = (size_t)h->cfg.num_envs * h->cfg.num_agents;
+    HIP_TRY(hipMalloc((void **)&h->d_arrive, cars * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(h->d_arrive, 0, cars * sizeof(uint32_t)));
     return F110_OK;
 }
 
@@ -318,7 +322,7 @@ extern "C" void f110_destroy(f110_handle *h)
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
     void *ptrs[] = {h->d_cs, h->d_beam_cs, h->d_noise_side, h->d_scan_angles, h->d_beam_cosines, h->d_side,
-                    h->d_chunk0, h->d_agent_params, h->d_opp_pairs, h->d_maps, h->d_env_map, h->d_order};
+                    h->d_chunk0, h->d_agent_params, h->d_opp_pairs, h->d_maps, h->d_env_map, h->d_order, h->d_arrive};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &sl : h->slots)
@@ -791,7 +795,7 @@ static ScanDev scan_dev(const f110_handle *h)
 
 // ev0 / ev1 (measurement aid, may be null): start / stop events attached to the dispatch itself, which costs
 // less than bracketing the launch with two hipEventRecord calls (those add two barrier packets to the queue)
-template <bool STEP>
+template <int SM>
 static int launch_scan_t(f110_handle *h, const ScanArgs &a, const Sink &k, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr)
 {
     int waves = 0;
@@ -800,10 +804,10 @@ static int launch_scan_t(f110_handle *h, const ScanArgs &a, const Sink &k, hipEv
     // sweeps only: F110_SCAN_PAD_LDS=<bytes> of unused dynamic LDS per workgroup caps the workgroups per CU (160 KiB / (8.6 KiB + pad)),
     // i.e. emulates a lower occupancy without touching the kernel
     static const unsigned pad_lds = getenv("F110_SCAN_PAD_LDS") ? (unsigned)atoi(getenv("F110_SCAN_PAD_LDS")) : 0u;
-    const void *f = h->ident && h->pow2 ? (const void *)&scan_kernel<true, true, STEP>
-                  : h->ident            ? (const void *)&scan_kernel<true, false, STEP>
-                  : h->pow2             ? (const void *)&scan_kernel<false, true, STEP>
-                                        : (const void *)&scan_kernel<false, false, STEP>;
+    const void *f = h->ident && h->pow2 ? (const void *)&scan_kernel<true, true, SM>
+                  : h->ident            ? (const void *)&scan_kernel<true, false, SM>
+                  : h->pow2             ? (const void *)&scan_kernel<false, true, SM>
+                                        : (const void *)&scan_kernel<false, false, SM>;
     return emit(k, f, grid, block, pad_lds, a, ev0, ev1);
 }
 
@@ -935,29 +939,31 @@ static int launch_scan(f110_handle *h, const ScanArgs &a_in, const Sink &st, hip
 #if defined(F110_TIMELINE)
     a.timeline = timeline_buffer();
 #endif
-    return a.state ? launch_scan_t<true>(h, a, st, ev0, ev1) : launch_scan_t<false>(h, a, st, ev0, ev1);
+    if (a.f.state) { // the closing form (one agent): the arrival counters of split cars
+        if (a.agents != 1 || !h->d_arrive) return fail(F110_E_INVALID, "scan launch: the closing form needs num_agents == 1");
+        a.arrive = h->d_arrive;
+        return launch_scan_t<2>(h, a, st, ev0, ev1);
+    }
+    return a.state ? launch_scan_t<1>(h, a, st, ev0, ev1) : launch_scan_t<0>(h, a, st, ev0, ev1);
 }
 
-// ---- car-group path (car_group_kernel): one workgroup of `waves` wavefronts per car
-// Which launches take it.  Measured on MI355X (profiles/r03_group_sweep.txt); F110_GROUP="waves[:max_cars]" overrides the
-// built-in choice for sweeps, f110_set_step_path for a handle.  Returns the wavefronts per car, 0 = classic path.
+// ---- car-group path (car_group_kernel): one workgroup of `waves` wavefronts per car.  Taken only on request
+// (f110_set_step_path(F110_PATH_GROUP), or F110_GROUP="waves[:max_cars]" for sweeps): measured on MI355X
+// (profiles/r03_group_*.txt) it matches the classic stage lists but does not beat them.  Returns the wavefronts per car.
 static int group_waves_for(const f110_handle *h, int n_cars)
 {
-    if (h->step_path == F110_PATH_CLASSIC) return 0;
     static const char *env = getenv("F110_GROUP");
-    int waves = 0, max_cars = 0; // (first measurement, gpurun_out/r03a: the fused form is slower at every size -- AUTO stays classic)
+    int waves = 0, max_cars = 0x7fffffff;
     if (env) {
         char *e = nullptr;
         waves = (int)strtol(env, &e, 10);
         if (e && *e == ':') max_cars = (int)strtol(e + 1, nullptr, 10);
+        if (waves == 0 && h->step_path != F110_PATH_GROUP) return 0; // F110_GROUP=0
     }
     if (h->group_waves) waves = h->group_waves;
-    if (h->step_path == F110_PATH_GROUP) max_cars = 0x7fffffff;
-    else if (env && waves == 0) return 0; // F110_GROUP=0: classic everywhere
-    if (n_cars > max_cars) return 0;
+    if (h->step_path != F110_PATH_GROUP && n_cars > max_cars) return 0;
     if (waves == 0) waves = n_cars <= 1024 ? 8 : 4;
-    waves = std::max(1, std::min(GROUP_MAX_WAVES, waves));
-    return waves;
+    return std::max(1, std::min(GROUP_MAX_WAVES, waves));
 }
 
 template <int MODE>
@@ -986,77 +992,96 @@ static int launch_group(f110_handle *h, const GroupArgs &a, int mode, int waves,
          : mode == 1 ? launch_group_t<1>(h, a, waves, st, ev0, ev1) : launch_group_t<0>(h, a, waves, st, ev0, ev1);
 }
 
+static void fill_scan_args(const f110_handle *h, ScanArgs &s, int reset_only)
+{
+    const f110_config &c = h->cfg;
+    const f110_buffers &b = h->bufs;
+    s.maps = h->d_maps; s.env_map = h->multi ? h->d_env_map : nullptr; s.scan = scan_dev(h); s.n_cars = c.num_envs * c.num_agents; s.agents = c.num_agents;
+    s.pose_src = b.state; s.pose_stride = 7; s.yaw_off = 4;
+    s.state = b.state; s.noise_step = b.noise_step; s.chunk_beam0 = h->d_chunk0;
+    s.noise_side = h->d_noise_side; s.noise_T = h->noise_T > 0 ? h->noise_T : 1;
+    s.beam_cosines = h->d_beam_cosines; s.ttc_thresh = c.ttc_thresh;
+    s.in_collision = b.in_collision; s.pending_reset = b.pending_reset; s.reset_only = reset_only;
+    s.out_f32 = b.scans; s.out_f64 = b.scans_f64; s.lookups = b.lookups;
+}
+
+static void fill_fuse_args(const f110_handle *h, FuseArgs &f, const double *actions)
+{
+    const f110_config &c = h->cfg;
+    const f110_buffers &b = h->bufs;
+    f.state = b.state; f.steer_buf = b.steer_buf; f.steer_cnt = b.steer_cnt; f.noise_step = b.noise_step; f.actions = actions;
+    f.spawn = b.spawn; f.pending_reset = b.pending_reset; f.pose_snap = b.pose_snap; f.in_collision = b.in_collision;
+    f.agent_params = h->d_agent_params; f.time_step = c.timestep; f.integrator = c.integrator; f.autoreset = c.autoreset;
+    f.collisions = b.collisions; f.collision_idx = b.collision_idx; f.start_rot = b.start_rot; f.near_start = b.near_start;
+    f.toggles = b.toggles; f.lap_counts = b.lap_counts; f.lap_times = b.lap_times; f.current_time = b.current_time;
+    f.done = b.done; f.checkpoint_done = b.checkpoint_done;
+}
+
+// The step of every env.  Forms (f110_set_step_path; AUTO picks by size, see step_form):
+//   classic  dynamics_kernel -> scan_kernel -> [opp_setup_kernel, opp_apply_kernel] -> env_kernel
+//   closed   dynamics_kernel -> scan_kernel<SM 2>, which also does env_kernel's work (one agent only)
+//   group    dynamics_kernel -> car_group_kernel (a workgroup per car; closing for one agent) [-> opponents -> env_kernel]
+enum StepForm { FORM_CLASSIC, FORM_CLOSED, FORM_GROUP };
+
+static StepForm step_form(const f110_handle *h, int n_cars, int *group_waves)
+{
+    *group_waves = 0;
+    if (h->step_path == F110_PATH_GROUP || (h->step_path == F110_PATH_AUTO && getenv("F110_GROUP"))) {
+        *group_waves = group_waves_for(h, n_cars);
+        if (*group_waves) return FORM_GROUP;
+    }
+    if (h->cfg.num_agents != 1 || h->step_path == F110_PATH_CLASSIC) return FORM_CLASSIC;
+    if (h->step_path == F110_PATH_CLOSED) return FORM_CLOSED;
+    // AUTO is classic at every size: measured on MI355X (profiles/r03_step_forms.txt) the closing scan is 2..9 %
+    // SLOWER than scan_kernel + env_kernel (a lane-per-env kernel of 5 us does the bookkeeping of 64 cars per wave
+    // instruction; one lane per car at the end of every wave does not), and the car groups only match the classic
+    // stage lists.  F110_CLOSED_MAX=<cars> makes AUTO take the closing scan up to that size (sweeps).
+    static const int closed_max = getenv("F110_CLOSED_MAX") ? atoi(getenv("F110_CLOSED_MAX")) : 0;
+    return n_cars <= closed_max ? FORM_CLOSED : FORM_CLASSIC;
+}
+
 static int run_step(f110_handle *h, const double *actions, int reset_only, const Sink &st)
 {
     const f110_config &c = h->cfg;
     const f110_buffers &b = h->bufs;
     const int N = c.num_envs * c.num_agents;
-    const int gw = group_waves_for(h, N);
+    int gw = 0;
+    const StepForm form = step_form(h, N, &gw);
     const bool prof = h->prof_on && (size_t)(2 * h->prof_n + 1) < h->prof_ev.size();
     hipEvent_t ev0 = prof ? h->prof_ev[2 * h->prof_n] : nullptr, ev1 = prof ? h->prof_ev[2 * h->prof_n + 1] : nullptr;
-    GroupArgs g;
-    memset(&g, 0, sizeof(g));
-    if (gw) {
-        ScanArgs &s = g.s;
-        s.maps = h->d_maps; s.env_map = h->multi ? h->d_env_map : nullptr; s.scan = scan_dev(h); s.n_cars = N; s.agents = c.num_agents;
-        s.pose_src = b.state; s.pose_stride = 7; s.yaw_off = 4;
-        s.state = b.state; s.noise_step = b.noise_step; s.chunk_beam0 = h->d_chunk0;
-        s.noise_side = h->d_noise_side; s.noise_T = h->noise_T > 0 ? h->noise_T : 1;
-        s.beam_cosines = h->d_beam_cosines; s.ttc_thresh = c.ttc_thresh;
-        s.in_collision = b.in_collision; s.pending_reset = b.pending_reset; s.reset_only = reset_only;
-        s.out_f32 = b.scans; s.out_f64 = b.scans_f64; s.lookups = b.lookups;
-    }
-    static const bool nofuse = getenv("F110_GROUP_NOFUSE") != nullptr; // sweeps: car groups for the scan only
+    static const bool nofuse = getenv("F110_GROUP_NOFUSE") != nullptr;     // sweeps: car groups for the scan only
     static const bool fuse_dyn = getenv("F110_GROUP_FUSE_DYN") != nullptr; // sweeps: update_pose inside the group kernel, per car
-    if (gw) g.order = h->d_order;
-    if (gw && c.num_agents == 1 && !nofuse) {
-        // one agent: the group kernel also closes the step (env_kernel's work by the last wave of each car); with
-        // fuse_dyn it integrates the car too (MODE 2: the whole step in one launch), else dynamics_kernel runs first
-        if (!fuse_dyn) {
-            DynArgs d;
-            d.n_cars = N; d.agents = c.num_agents; d.state = b.state; d.steer_buf = b.steer_buf; d.steer_cnt = b.steer_cnt;
-            d.noise_step = b.noise_step; d.actions = actions; d.spawn = b.spawn; d.pending_reset = b.pending_reset;
-            d.reset_only = reset_only; d.pose_snap = b.pose_snap; d.in_collision = b.in_collision; d.agent_params = h->d_agent_params;
-            d.time_step = c.timestep; d.integrator = c.integrator;
-            int rc = emit(st, (const void *)&dynamics_kernel, dim3((N + 255) / 256), dim3(256), 0, d);
-            if (rc) return rc;
-        }
-        FuseArgs &f = g.f;
-        f.state = b.state; f.steer_buf = b.steer_buf; f.steer_cnt = b.steer_cnt; f.noise_step = b.noise_step; f.actions = actions;
-        f.spawn = b.spawn; f.pending_reset = b.pending_reset; f.pose_snap = b.pose_snap; f.in_collision = b.in_collision;
-        f.agent_params = h->d_agent_params; f.time_step = c.timestep; f.integrator = c.integrator; f.autoreset = c.autoreset;
-        f.collisions = b.collisions; f.collision_idx = b.collision_idx; f.start_rot = b.start_rot; f.near_start = b.near_start;
-        f.toggles = b.toggles; f.lap_counts = b.lap_counts; f.lap_times = b.lap_times; f.current_time = b.current_time;
-        f.done = b.done; f.checkpoint_done = b.checkpoint_done;
-        int rc = launch_group(h, g, fuse_dyn ? 2 : 3, gw, st, ev0, ev1);
-        if (rc) return rc;
-        if (prof) h->prof_n++;
-        return F110_OK;
-    }
-    DynArgs d;
-    d.n_cars = N; d.agents = c.num_agents; d.state = b.state; d.steer_buf = b.steer_buf; d.steer_cnt = b.steer_cnt;
-    d.noise_step = b.noise_step; d.actions = actions; d.spawn = b.spawn; d.pending_reset = b.pending_reset;
-    d.reset_only = reset_only; d.pose_snap = b.pose_snap; d.in_collision = b.in_collision; d.agent_params = h->d_agent_params; d.time_step = c.timestep;
-    d.integrator = c.integrator;
-    int rc = emit(st, (const void *)&dynamics_kernel, dim3((N + 255) / 256), dim3(256), 0, d);
-    if (rc) return rc;
+    const bool closing = c.num_agents == 1 && (form == FORM_CLOSED || (form == FORM_GROUP && !nofuse));
+    int rc;
 
-    if (gw) rc = launch_group(h, g, 1, gw, st, ev0, ev1);
-    else {
+    if (!(form == FORM_GROUP && closing && fuse_dyn)) {
+        DynArgs d;
+        d.n_cars = N; d.agents = c.num_agents; d.state = b.state; d.steer_buf = b.steer_buf; d.steer_cnt = b.steer_cnt;
+        d.noise_step = b.noise_step; d.actions = actions; d.spawn = b.spawn; d.pending_reset = b.pending_reset;
+        d.reset_only = reset_only; d.pose_snap = b.pose_snap; d.in_collision = b.in_collision; d.agent_params = h->d_agent_params;
+        d.time_step = c.timestep; d.integrator = c.integrator;
+        if ((rc = emit(st, (const void *)&dynamics_kernel, dim3((N + 255) / 256), dim3(256), 0, d))) return rc;
+    }
+
+    // the scan (the launch the measurement aid brackets)
+    if (form == FORM_GROUP) {
+        GroupArgs g;
+        memset(&g, 0, sizeof(g));
+        fill_scan_args(h, g.s, reset_only);
+        g.order = h->d_order;
+        if (closing) fill_fuse_args(h, g.s.f, actions);
+        rc = launch_group(h, g, closing ? (fuse_dyn ? 2 : 3) : 1, gw, st, ev0, ev1);
+    } else {
         ScanArgs s;
         memset(&s, 0, sizeof(s));
-        s.maps = h->d_maps; s.env_map = h->multi ? h->d_env_map : nullptr; s.scan = scan_dev(h); s.n_cars = N; s.agents = c.num_agents;
-        s.pose_src = b.state; s.pose_stride = 7; s.yaw_off = 4;
-        s.state = b.state; s.noise_step = b.noise_step; s.chunk_beam0 = h->d_chunk0;
-        s.noise_side = h->d_noise_side; s.noise_T = h->noise_T > 0 ? h->noise_T : 1;
-        s.beam_cosines = h->d_beam_cosines;
-        s.ttc_thresh = c.ttc_thresh;
-        s.in_collision = b.in_collision; s.pending_reset = b.pending_reset; s.reset_only = reset_only;
-        s.out_f32 = b.scans; s.out_f64 = b.scans_f64; s.lookups = b.lookups;
+        fill_scan_args(h, s, reset_only);
+        if (closing) fill_fuse_args(h, s.f, actions);
         rc = launch_scan(h, s, st, ev0, ev1);
     }
     if (rc) return rc;
     if (prof) h->prof_n++;
+    if (closing) return F110_OK;
+
     if (c.num_agents > 1) {
         OppArgs o;
         o.n_cars = N; o.agents = c.num_agents; o.nb = c.num_beams; o.state = b.state; o.pose_snap = b.pose_snap;
@@ -1238,8 +1263,10 @@ extern "C" int f110_set_scan_stages(f110_handle *h, const char *spec)
 extern "C" int f110_set_step_path(f110_handle *h, int32_t path, int32_t waves_per_car)
 {
     if (!h) return fail(F110_E_INVALID, "f110_set_step_path: null handle");
-    if (path != F110_PATH_AUTO && path != F110_PATH_CLASSIC && path != F110_PATH_GROUP)
-        return fail(F110_E_INVALID, "f110_set_step_path: path %d (0 auto, 1 classic, 2 car groups)", path);
+    if (path != F110_PATH_AUTO && path != F110_PATH_CLASSIC && path != F110_PATH_GROUP && path != F110_PATH_CLOSED)
+        return fail(F110_E_INVALID, "f110_set_step_path: path %d (0 auto, 1 classic, 2 car groups, 3 closing scan)", path);
+    if (path == F110_PATH_CLOSED && h->cfg.num_agents != 1)
+        return fail(F110_E_INVALID, "f110_set_step_path: the closing scan needs num_agents == 1 (the handle has %d)", h->cfg.num_agents);
     if (waves_per_car < 0 || waves_per_car > GROUP_MAX_WAVES)
         return fail(F110_E_INVALID, "f110_set_step_path: %d wavefronts per car (0 = built-in choice, 1..%d)", waves_per_car, GROUP_MAX_WAVES);
     h->step_path = path;
@@ -1418,7 +1445,8 @@ extern "C" int f110_scan(f110_handle *h, const double *poses, int32_t n, double 
     s.maps = h->d_maps; s.scan = scan_dev(h); s.n_cars = n; s.agents = 1;
     s.pose_src = poses; s.pose_stride = 3; s.yaw_off = 2;
     s.out_f32 = out32; s.out_f64 = out64; s.lookups = lookups; s.noise_T = 1; s.chunk_beam0 = h->d_chunk0;
-    if (const int gw = group_waves_for(h, n)) {
+    int gw = 0;
+    if (step_form(h, n, &gw) == FORM_GROUP) {
         GroupArgs g;
         memset(&g, 0, sizeof(g));
         g.s = s;

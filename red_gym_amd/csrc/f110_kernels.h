@@ -206,6 +206,33 @@ __device__ inline int beam_theta_index(unsigned long long T0, double t0w, int b,
     return idx;
 }
 
+// What dynamics_kernel and env_kernel take: used by the scan kernels that also close the step of a one-agent env
+// (scan_kernel SM 2, car_group_kernel MODE 2 / 3).
+struct FuseArgs {
+    double *state;              // [N,7]
+    double *steer_buf;          // [N,2]
+    int32_t *steer_cnt;         // [N]
+    int32_t *noise_step;        // [N]
+    const double *actions;      // [N,2] or NULL (reset)
+    const double *spawn;        // [N,3]
+    uint8_t *pending_reset;     // [B]
+    double *pose_snap;          // [N,3]
+    uint8_t *in_collision;      // [N]
+    const Params *agent_params;
+    double time_step;
+    int integrator, autoreset;
+    uint8_t *collisions;        // [N]
+    int32_t *collision_idx;     // [N]
+    double *start_rot;          // [B,4]
+    uint8_t *near_start;        // [N]
+    int32_t *toggles;           // [N]
+    int32_t *lap_counts;        // [N]
+    double *lap_times;          // [N]
+    double *current_time;       // [B]
+    uint8_t *done;              // [B]
+    uint8_t *checkpoint_done;   // [N] or NULL
+};
+
 struct ScanArgs {
     const MapDev *maps;         // dev [K] map descriptors
     const int32_t *env_map;     // dev [B] map of every env, or NULL (all envs on maps[0]); the cars of one
@@ -238,6 +265,8 @@ struct ScanArgs {
     float *out_f32;              // [N,nb] or NULL
     double *out_f64;             // [N,nb] or NULL
     uint32_t *lookups;           // [N] or NULL (accumulated)
+    FuseArgs f;                  // closing kernels only (else zero)
+    uint32_t *arrive;            // [N] closing scan_kernel: waves of a split car that have finished (+ 0x10000 per wave with an iTTC hit); zero between launches
     unsigned long long *timeline; // diagnostics (builds with -DF110_TIMELINE only, tools/timeline.py): per wave
                                   // {start, rays started, end} in 100 MHz ticks and (car << 8 | part); else NULL
 };
@@ -259,12 +288,18 @@ static_assert(sizeof(((ScanArgs *)0)->stage_cars) == SCAN_MAX_STAGES * sizeof(in
               sizeof(((ScanArgs *)0)->stage_log2w) == SCAN_MAX_STAGES * sizeof(int), "stage list capacity");
 static_assert(sizeof(ScanArgs) <= 4096, "kernarg segment size");
 
-template <bool IDENT, bool POW2, bool STEP>
+__device__ inline void close_car_step(const FuseArgs *F, int car, bool pend, bool anyhit, int row, double st[7], bool write_state); // (below)
+
+// SM 0: ScanSimulator2D.scan(pose, None); 1: the scan of a step (noise, iTTC flag; env_kernel follows); 2: the scan of
+// a ONE-AGENT step that also closes it: the last wave of a car to finish (a per-car arrival counter when the car is
+// split over several waves) does env_kernel's work for that car, so the step is dynamics_kernel + this launch.
+template <bool IDENT, bool POW2, int SM>
 #ifndef F110_SCAN_MIN_WAVES
 #define F110_SCAN_MIN_WAVES 8
 #endif
 __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel(ScanArgs a)
 {
+    constexpr bool STEP = SM >= 1, CLOSE = SM == 2;
     __shared__ __attribute__((aligned(16))) double s_lut[LUT_LDS];
     __shared__ int s_chunk0[MAX_CHUNKS];
     // the same argument block addressed through the kernarg segment (ScanArgs is the only kernel argument): rarely
@@ -449,8 +484,28 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
 
     // ---- iTTC result: the flag only; env_kernel zeroes the state (base_classes.py:241-250)
     // once every wave of the car is done.  Plain store: all writers store the same 1.
-    if (STEP) {
+    if (STEP && !CLOSE) {
         if (vote(hit) != 0ull && lane == 0) ra->in_collision[car] = 1;
+    }
+    if (CLOSE) {
+        // A == 1 (env == car).  The last of the car's waves to get here closes its step.  The counter also carries the
+        // waves' iTTC hits, so nothing but the atomic itself has to be visible across CUs; it is zero again afterwards.
+        const bool whit = vote(hit) != 0ull;
+        bool last = true, anyhit = whit;
+        if (wpc > 1) {
+            unsigned old = 0;
+            if (lane == 0) old = atomicAdd(&ra->arrive[car], 1u | (whit ? 0x10000u : 0u));
+            old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
+            last = (int)(old & 0xffffu) == wpc - 1;
+            anyhit = whit || (old >> 16) != 0u;
+        }
+        if (!last || lane != 0) return;
+        if (wpc > 1) ra->arrive[car] = 0;
+        const FuseArgs *F = &ra->f;
+        double st[7];
+#pragma unroll
+        for (int i = 0; i < 7; i++) st[i] = F->state[(size_t)car * 7 + i]; // written by dynamics_kernel, read-only in this launch until here
+        close_car_step(F, car, F->pending_reset[car] != 0, anyhit, F->noise_step[car], st, false);
     }
 }
 
@@ -475,30 +530,48 @@ __device__ inline bool check_done_dev(const double *xy, int stride, const double
                                       double r10, double r11, double current_time, uint8_t *near_start, int32_t *toggles,
                                       int32_t *lap_counts, double *lap_times, uint8_t *checkpoint_done); // (below)
 
-struct FuseArgs {               // MODE 2 only: what dynamics_kernel and env_kernel take
-    double *state;              // [N,7]
-    double *steer_buf;          // [N,2]
-    int32_t *steer_cnt;         // [N]
-    int32_t *noise_step;        // [N]
-    const double *actions;      // [N,2] or NULL (reset)
-    const double *spawn;        // [N,3]
-    uint8_t *pending_reset;     // [B]
-    double *pose_snap;          // [N,3]
-    uint8_t *in_collision;      // [N]
-    const Params *agent_params;
-    double time_step;
-    int integrator, autoreset;
-    uint8_t *collisions;        // [N]
-    int32_t *collision_idx;     // [N]
-    double *start_rot;          // [B,4]
-    uint8_t *near_start;        // [N]
-    int32_t *toggles;           // [N]
-    int32_t *lap_counts;        // [N]
-    double *lap_times;          // [N]
-    double *current_time;       // [B]
-    uint8_t *done;              // [B]
-    uint8_t *checkpoint_done;   // [N] or NULL
-};
+// env_kernel's work for ONE car of a one-agent env, done by the last wave of the car to finish its rays: the iTTC
+// state update (base_classes.py:244-247), collision flags (:581-582; no other car, so Simulator.check_collision finds
+// nothing), noise row, F110Env.reset bookkeeping for a pending env (f110_env.py:318-329), time, lap logic and done
+// (:292-302), autoreset arming.  st: the car's state after integration; write_state: store it even without a hit.
+__device__ inline void close_car_step(const FuseArgs *F, int car, bool pend, bool anyhit, int row, double st[7], bool write_state)
+{
+    const int env = car;
+    if (anyhit) { st[3] = 0.; st[4] = 0.; st[5] = 0.; st[6] = 0.; } // check_ttc, base_classes.py:244-247
+    if (write_state || anyhit) {
+#pragma unroll
+        for (int i = 0; i < 7; i++) F->state[(size_t)car * 7 + i] = st[i];
+    }
+    F->noise_step[car] = row + 1;                 // one noise row consumed per scan
+    F->in_collision[car] = anyhit ? 1 : 0;
+    F->collisions[car] = anyhit ? 1 : 0;          // no other car: Simulator.check_collision finds nothing (:529-543), :581-582
+    F->collision_idx[car] = -1;
+    double ct = F->current_time[env];
+    double r00, r01, r10, r11;
+    if (pend) {
+        // F110Env.reset (f110_env.py:318-329)
+        ct = 0.0;
+        const double th = -F->spawn[(size_t)car * 3 + 2];
+        r00 = cos(th); r01 = -sin(th); r10 = sin(th); r11 = cos(th);
+        F->start_rot[(size_t)env * 4] = r00; F->start_rot[(size_t)env * 4 + 1] = r01;
+        F->start_rot[(size_t)env * 4 + 2] = r10; F->start_rot[(size_t)env * 4 + 3] = r11;
+        F->near_start[car] = 1; F->toggles[car] = 0;
+    } else {
+        r00 = F->start_rot[(size_t)env * 4]; r01 = F->start_rot[(size_t)env * 4 + 1];
+        r10 = F->start_rot[(size_t)env * 4 + 2]; r11 = F->start_rot[(size_t)env * 4 + 3];
+    }
+    ct = ct + F->time_step; // f110_env.py:293
+    F->current_time[env] = ct;
+    const bool all_done = check_done_dev(st, 7, F->spawn + (size_t)car * 3, 1, r00, r01, r10, r11, ct, F->near_start + car,
+                                         F->toggles + car, F->lap_counts + car, F->lap_times + car,
+                                         F->checkpoint_done ? F->checkpoint_done + car : nullptr);
+    const bool dn = anyhit || all_done;
+    F->done[env] = dn ? 1 : 0;
+    F->pending_reset[env] = (F->autoreset && dn) ? 1 : 0;
+}
+
+
+
 
 // Per car, from its previous scan: the order in which its 64-beam chunks are handed out, longest-lived rays first,
 // and how long its longest ray lived.  A hint only -- any permutation of the full chunks gives the same bits -- but
@@ -513,7 +586,6 @@ constexpr int ORDER_AGE = MAX_CHUNKS, ORDER_VALID = MAX_CHUNKS + 1;
 
 struct GroupArgs {
     ScanArgs s;                 // wpc / stage list unused: the grid is one workgroup per car
-    FuseArgs f;
     uint16_t *order;            // [N, ORDER_STRIDE] or NULL (static order, nothing recorded)
 };
 static_assert(__is_trivially_copyable(GroupArgs) && offsetof(GroupArgs, s) == 0 && sizeof(GroupArgs) <= 4096,
@@ -584,7 +656,7 @@ __global__ __launch_bounds__(GROUP_MAX_WAVES * WAVE, F110_GROUP_MIN_WAVES) void 
     if (FUSED && wave == 0) {
         // RaceCar.update_pose (base_classes.py:254-402) from the OLD state, or RaceCar.reset (:181-202) followed by
         // the zero-action step of F110Env.reset (f110_env.py:335-336): what dynamics_kernel does for this car
-        const FuseArgs *F = &rare->f;
+        const FuseArgs *F = &rare->s.f;
         asm volatile("" : "+s"(F));
         double st[7], sb[2], steer, speed;
         int sc, row;
@@ -797,7 +869,7 @@ __global__ __launch_bounds__(GROUP_MAX_WAVES * WAVE, F110_GROUP_MIN_WAVES) void 
     if (!CLOSE) return;
     if (lane != 0) return;
     const bool anyhit = whit || (old >> 16) != 0u;
-    const FuseArgs *F = &ra->f;
+    const FuseArgs *F = &ra->s.f;
     double st[7];
     if (FUSED) {
 #pragma unroll
@@ -814,37 +886,7 @@ __global__ __launch_bounds__(GROUP_MAX_WAVES * WAVE, F110_GROUP_MIN_WAVES) void 
 #pragma unroll
         for (int i = 0; i < 7; i++) st[i] = F->state[(size_t)car * 7 + i];
     }
-    if (anyhit) { st[3] = 0.; st[4] = 0.; st[5] = 0.; st[6] = 0.; } // check_ttc, base_classes.py:244-247
-    if (FUSED || anyhit) {
-#pragma unroll
-        for (int i = 0; i < 7; i++) F->state[(size_t)car * 7 + i] = st[i];
-    }
-    F->noise_step[car] = row + 1;                 // one noise row consumed per scan
-    F->in_collision[car] = anyhit ? 1 : 0;
-    F->collisions[car] = anyhit ? 1 : 0;          // no other car: Simulator.check_collision finds nothing (:529-543), :581-582
-    F->collision_idx[car] = -1;
-    double ct = F->current_time[env];
-    double r00, r01, r10, r11;
-    if (pend) {
-        // F110Env.reset (f110_env.py:318-329)
-        ct = 0.0;
-        const double th = -F->spawn[(size_t)car * 3 + 2];
-        r00 = cos(th); r01 = -sin(th); r10 = sin(th); r11 = cos(th);
-        F->start_rot[(size_t)env * 4] = r00; F->start_rot[(size_t)env * 4 + 1] = r01;
-        F->start_rot[(size_t)env * 4 + 2] = r10; F->start_rot[(size_t)env * 4 + 3] = r11;
-        F->near_start[car] = 1; F->toggles[car] = 0;
-    } else {
-        r00 = F->start_rot[(size_t)env * 4]; r01 = F->start_rot[(size_t)env * 4 + 1];
-        r10 = F->start_rot[(size_t)env * 4 + 2]; r11 = F->start_rot[(size_t)env * 4 + 3];
-    }
-    ct = ct + F->time_step; // f110_env.py:293
-    F->current_time[env] = ct;
-    const bool all_done = check_done_dev(st, 7, F->spawn + (size_t)car * 3, 1, r00, r01, r10, r11, ct, F->near_start + car,
-                                         F->toggles + car, F->lap_counts + car, F->lap_times + car,
-                                         F->checkpoint_done ? F->checkpoint_done + car : nullptr);
-    const bool dn = anyhit || all_done;
-    F->done[env] = dn ? 1 : 0;
-    F->pending_reset[env] = (F->autoreset && dn) ? 1 : 0;
+    close_car_step(F, car, pend, anyhit, row, st, FUSED);
 }
 
 // ------------------------------------------------------------------ opponents (A > 1)

@@ -121,6 +121,8 @@ class Engine(object):
         forced = os.environ.get('F110_STEP_PATH')  # 'classic' | 'group[:waves]' (test suite / sweeps)
         if forced:
             name, _, w = forced.partition(':')
+            if name == 'closed' and self.A != 1:
+                name = 'classic'  # the closing scan exists for one agent only
             self.set_step_path(name, int(w or 0))
 
     # ------------------------------------------------------------------ buffers
@@ -374,9 +376,9 @@ class Engine(object):
 
     def set_step_path(self, path='auto', waves_per_car=0):
         """Which kernels a step enqueues (f110_set_step_path): 'classic' = dynamics -> scan (wave per car) -> env,
-        'group' = one workgroup of `waves_per_car` wavefronts per car (the whole step in one launch for one agent),
-        'auto' = groups for small launches.  Results do not depend on it."""
-        code = {'auto': 0, 'classic': 1, 'group': 2}[path]
+        'closed' = dynamics -> scan that also does the env bookkeeping (one agent), 'group' = one workgroup of
+        `waves_per_car` wavefronts per car, 'auto' = closed for small one-agent launches.  Results do not depend on it."""
+        code = {'auto': 0, 'classic': 1, 'group': 2, 'closed': 3}[path]
         _lib.check(self.lib.f110_set_step_path(self._h, code, int(waves_per_car)))
 
     def launch_epoch(self):

@@ -14,11 +14,12 @@ def _np(t):
     return t.detach().cpu().numpy()
 
 
-@pytest.fixture(autouse=True, params=['classic', 'group'])
+@pytest.fixture(autouse=True, params=['classic', 'closed', 'group'])
 def step_path(request, monkeypatch):
-    """Every test of this module runs on both step paths (f110_set_step_path): 'classic' = dynamics_kernel ->
-    scan_kernel -> [opponents] -> env_kernel, 'group' = a workgroup per car (the whole step in ONE launch for one
-    agent).  The engine reads F110_STEP_PATH when it is built."""
+    """Every test of this module runs on all step paths (f110_set_step_path): 'classic' = dynamics_kernel ->
+    scan_kernel -> [opponents] -> env_kernel; 'closed' = dynamics_kernel -> scan_kernel that also does the env
+    bookkeeping (one agent; more agents fall back to classic); 'group' = a workgroup per car.  The engine reads
+    F110_STEP_PATH when it is built."""
     monkeypatch.setenv('F110_STEP_PATH', request.param)
     return request.param
 
@@ -522,13 +523,17 @@ def test_scan_stage_lists_give_identical_results(assets, spec, A):
     e1.close(); e2.close()
 
 
-@pytest.mark.parametrize('waves', [1, 2, 3, 4, 8])
+@pytest.mark.parametrize('form', ['closed', 'closed:*:2', 'closed:10:0,*:3', 'group:1', 'group:2', 'group:3', 'group:4', 'group:8'])
 @pytest.mark.parametrize('A', [1, 2])
-def test_step_paths_give_identical_results(assets, waves, A):
-    """The car-group path (one workgroup of `waves` wavefronts per car drawing beams from one queue; for one agent the
-    whole step -- update_pose in front, env bookkeeping behind -- in that one launch) against the classic three-kernel
-    path: every buffer a step writes `==` over 60 autoreset steps with wall hits, cars inside walls / off the map and
-    a masked reset in between; then the function-level scan."""
+def test_step_paths_give_identical_results(assets, form, A):
+    """The closing scan (the last wave of a car -- whole cars and cars split over 2 / 4 / 8 waves by a stage list --
+    does the env bookkeeping) and the car-group path (one workgroup of 1..8 wavefronts per car drawing beams from one
+    queue, its order learnt from the previous scan) against the classic three-kernel path: every buffer a step writes
+    `==` over 60 autoreset steps with wall hits, cars inside walls / off the map and a masked reset in between; then
+    the function-level scan."""
+    name, _, rest = form.partition(':')
+    if name == 'closed' and A != 1:
+        pytest.skip('the closing scan exists for one agent')
     import torch
     from red_gym_amd import workload
     B, T = 37, 60
@@ -543,7 +548,12 @@ def test_step_paths_give_identical_results(assets, waves, A):
     e1 = _vec(assets, B, A, autoreset=True, count_lookups=True)
     e2 = _vec(assets, B, A, autoreset=True, count_lookups=True)
     e1.eng.set_step_path('classic')
-    e2.eng.set_step_path('group', waves)
+    if name == 'group':
+        e2.eng.set_step_path('group', int(rest))
+    else:
+        e2.eng.set_step_path('closed')
+        if rest:
+            e2.eng.set_scan_stages(rest)
     e1.reset(poses); e2.reset(poses)
     keys = [k for k in e1.eng.t if e1.eng.t[k] is not None]
     hits = 0

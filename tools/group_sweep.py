@@ -16,7 +16,7 @@ ap.add_argument('sizes', nargs='*', type=int, default=[1024, 2048, 4096, 8192, 1
 ap.add_argument('--agents', type=int, default=1)
 ap.add_argument('--steps', type=int, default=200)
 ap.add_argument('--warmup', type=int, default=60)
-ap.add_argument('--paths', default='classic,group:2,group:4,group:8')
+ap.add_argument('--paths', default='classic,closed,group:2,group:4')
 a = ap.parse_args()
 for B in a.sizes:
     ref = None
