@@ -243,6 +243,9 @@ def main(argv=None):
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-scan-events', action='store_true',
                     help='do not bracket the scan kernel with hipEvents (roofline becomes null)')
+    ap.add_argument('--scan-events-every', type=int, default=4,
+                    help='hipEvent pairs ride on the scan dispatch of every Nth TIMED step (a dispatch with events costs '
+                         'the stream ~10 us of idle time around it); 1 = every step')
     args = ap.parse_args(argv)
     if args.gpus < 1:
         ap.error('--gpus must be >= 1')
@@ -315,7 +318,7 @@ def main(argv=None):
         step_fn(0)
         lookups.zero_()
     if not args.no_scan_events:
-        env.eng.profile_begin(K)  # hipEvent pair around each of the K timed scan launches
+        env.eng.profile_begin(K, every=max(1, args.scan_events_every))  # hipEvent pairs on every Nth timed scan launch
     elapsed = timed_steps(ranks, step_fn, K)
     scan_prof = env.eng.profile_end() if not args.no_scan_events else None  # the K timed launches only
     tot_lookups = int(lookups.to(torch.int64).sum().item())                  # ... and their table reads
@@ -335,7 +338,7 @@ def main(argv=None):
             scan_ms, n_launch = scan_prof
             cars = B * A
             # SURVEY 8(d) byte model, per car-step: L*4 + 1080*4 + 72
-            bytes_per_launch = (tot_lookups / max(n_launch, 1)) * 4.0 + cars * (1080 * 4 + 72)
+            bytes_per_launch = (tot_lookups / K) * 4.0 + cars * (1080 * 4 + 72)  # lookups: mean over ALL K timed launches
             avg_s = scan_ms * 1e-3 / max(n_launch, 1)
             achieved = bytes_per_launch / avg_s / 1e9
             # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE in separate
@@ -354,7 +357,7 @@ def main(argv=None):
             roof = {'bound': 'hbm', 'kernel': 'scan_kernel', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                     'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                     'avg_launch_ms': avg_s * 1e3, 'launches': n_launch,
-                    'lookups_per_car_step': tot_lookups / max(n_launch, 1) / cars,
+                    'lookups_per_car_step': tot_lookups / K / cars, 'events_every': max(1, args.scan_events_every),
                     'algorithmic_bytes_per_launch': bytes_per_launch,
                     'model': 'SURVEY 8(d) algorithmic bytes: lookups*4 + cars*(1080*4 + 72), not HBM traffic',
                     'measured_hbm_gbs': (traffic / avg_s / 1e9) if traffic else None,

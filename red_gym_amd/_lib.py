@@ -76,6 +76,7 @@ SYMBOLS = {
     'f110_pure_pursuit_workspace': [_I32, _I32],
     'f110_pure_pursuit_tracks': [_VP, _VP, _VP, _VP, _I32, _VP, _D, _D, _D, _D, _VP, _I32, _VP, _VP, _I32, _VP],
     'f110_profile_begin': [_VP, _I32],
+    'f110_profile_every': [_VP, _I32],
     'f110_profile_end': [_VP, C.POINTER(C.c_double), C.POINTER(C.c_int32)],
     'f110_scan': [_VP, _VP, _I32, _VP, _VP, _VP, _VP],
     'f110_update_pose': [_VP, _VP, _VP, _VP, _VP, _I32, _VP],

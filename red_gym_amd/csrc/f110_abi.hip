@@ -84,7 +84,7 @@ struct f110_handle {
     double theta_inc = 0;
     // measurement aid (f110_profile_begin/end)
     std::vector<hipEvent_t> prof_ev; // pairs: [2*i] before, [2*i+1] after the scan launch
-    int prof_n = 0;
+    int prof_n = 0, prof_every = 1, prof_seq = 0; // events ride on every prof_every-th step's scan launch
     bool prof_on = false;
 };
 
@@ -1047,7 +1047,7 @@ static int run_step(f110_handle *h, const double *actions, int reset_only, const
     const int N = c.num_envs * c.num_agents;
     int gw = 0;
     const StepForm form = step_form(h, N, &gw);
-    const bool prof = h->prof_on && (size_t)(2 * h->prof_n + 1) < h->prof_ev.size();
+    const bool prof = h->prof_on && !st.record && (h->prof_seq++ % h->prof_every) == 0 && (size_t)(2 * h->prof_n + 1) < h->prof_ev.size();
     hipEvent_t ev0 = prof ? h->prof_ev[2 * h->prof_n] : nullptr, ev1 = prof ? h->prof_ev[2 * h->prof_n + 1] : nullptr;
     static const bool nofuse = getenv("F110_GROUP_NOFUSE") != nullptr;     // sweeps: car groups for the scan only
     static const bool fuse_dyn = getenv("F110_GROUP_FUSE_DYN") != nullptr; // sweeps: update_pose inside the group kernel, per car
@@ -1291,11 +1291,19 @@ static void prof_clear(f110_handle *h)
     h->prof_on = false;
 }
 
+extern "C" int f110_profile_every(f110_handle *h, int32_t every)
+{
+    if (!h || every < 1) return fail(F110_E_INVALID, "f110_profile_every: bad arguments");
+    h->prof_every = every;
+    return F110_OK;
+}
+
 extern "C" int f110_profile_begin(f110_handle *h, int32_t max_launches)
 {
     if (!h || max_launches < 1 || max_launches > (1 << 20)) return fail(F110_E_INVALID, "f110_profile_begin: bad arguments");
     HIP_TRY(hipSetDevice(h->cfg.device));
     prof_clear(h);
+    h->prof_seq = 0;
     h->prof_ev.resize((size_t)2 * max_launches);
     for (auto &e : h->prof_ev) HIP_TRY(hipEventCreate(&e));
     h->prof_on = true;

@@ -904,6 +904,8 @@ struct OppPair {
     double qx, qy, reach;  // opponent centre relative to the ego, padded half diagonal: a ray whose line passes
                            // the centre at more than `reach` cannot cross an edge (conservative pre-test, see opp_apply)
     int lo, hi;            // get_blocked_view_indices span (lo > hi: nothing to do)
+    unsigned long long chunks; // bit c: the 64-beam chunk c of [lo, hi] holds beams whose LINE passes the opponent's bounding
+                               // circle (a chunk-granular form of opp_apply's per-beam pre-test: the other chunks are skipped)
 };
 
 struct OppArgs {
@@ -929,7 +931,7 @@ __global__ __launch_bounds__(128) void opp_setup_kernel(OppArgs a)
     const int car = p / per, jj = p % per;
     const int env = car / a.agents, a0 = env * a.agents, self = car - a0;
     OppPair &o = a.pairs[p];
-    if (a.reset_only && !a.pending_reset[env]) { o.lo = 1; o.hi = 0; return; }
+    if (a.reset_only && !a.pending_reset[env]) { o.lo = 1; o.hi = 0; o.chunks = 0ull; return; }
     const int j = jj < self ? jj : jj + 1; // opponents in agent order, skipping the car itself (:574)
     const double *st = a.state + (size_t)car * 7;
     // an iTTC hit zeroes the yaw before the ray cast (base_classes.py:245); env_kernel applies it
@@ -967,6 +969,37 @@ __global__ __launch_bounds__(128) void opp_setup_kernel(OppArgs a)
         if (!(o.reach == o.reach)) o.reach = __builtin_inf(); // NaN poses: no pre-test
     }
     o.lo = lo; o.hi = hi;
+    // Which chunks can matter.  A beam can only be cut short if its line passes within `reach` of the opponent's
+    // centre (opp_apply's pre-test), i.e. if its direction, modulo pi, is within asin(reach / |q|) of the direction to
+    // the centre.  With the opponent straight behind the car the reference's span is the whole scan (the corner
+    // angles straddle +-pi, laser_models.py:293-315) although only a few dozen beams point at it or away from it:
+    // opp_apply then walks 2..4 chunks instead of 17.  Conservative (margins of a beam increment and 1e-6 rad), so the
+    // beams tested inside the visited chunks -- and the results -- are those of the per-beam pre-test alone.
+    unsigned long long mask = 0ull;
+    if (lo <= hi) {
+        const double qn = sqrt(o.qx * o.qx + o.qy * o.qy);
+        const double sa0 = a.scan_angles[0];
+        const double incr = (a.scan_angles[a.nb - 1] - sa0) / (double)(a.nb - 1);
+        const bool all = !(qn > o.reach * 1.000001) || !(o.reach < __builtin_inf()) || !(incr > 0.0);
+        if (all) {
+            for (int c = lo >> 6; c <= (hi >> 6); c++) mask |= 1ull << c;
+        } else {
+            const double span = asin(o.reach / qn) + 2.0 * incr + 1e-6;
+            const double phi = remainder(atan2(o.qy, o.qx) - pyaw, 2.0 * F110_PI); // direction to the centre in the scan's frame
+            const double inv = 1.0 / incr;
+            // the direction, its opposite (lines, not rays) and their images one turn away: beam-index intervals
+            for (int k = -2; k <= 2; k++) {
+                const double centre = phi + (double)k * F110_PI;
+                const double a0 = (centre - span - sa0) * inv, a1 = (centre + span - sa0) * inv;
+                if (!(a1 >= (double)lo) || !(a0 <= (double)hi)) continue;
+                const int i0 = a0 > (double)lo ? (int)floor(a0) : lo, i1 = a1 < (double)hi ? (int)ceil(a1) : hi;
+                if (i0 > i1) continue;
+                const int c0 = i0 >> 6, c1 = i1 >> 6;
+                mask |= (~0ull >> (63 - c1)) & ~((1ull << c0) - 1ull);
+            }
+        }
+    }
+    o.chunks = mask;
 }
 
 // One wave per car, walking the 64-beam chunks that some opponent's span touches (most cars see their
@@ -978,18 +1011,18 @@ __global__ __launch_bounds__(256) void opp_apply_kernel(OppArgs a)
     if (car >= a.n_cars) return;
     const int lane = threadIdx.x & 63, per = a.agents - 1;
     const OppPair *pairs = a.pairs + (size_t)car * per; // wave-uniform: scalar loads
-    int lo = a.nb, hi = -1;
-    for (int jj = 0; jj < per; jj++) {
-        const int l = pairs[jj].lo, h = pairs[jj].hi;
-        if (l <= h) { lo = min(lo, l); hi = max(hi, h); }
-    }
-    hi = min(hi, a.nb - 1);
-    for (int base = lo & ~63; base <= hi; base += 64) {
+    unsigned long long todo = 0ull; // chunks some opponent's span touches AND whose beams can reach it (opp_setup)
+    for (int jj = 0; jj < per; jj++)
+        if (pairs[jj].lo <= pairs[jj].hi) todo |= pairs[jj].chunks;
+    while (todo) {
+        const int chunk = (int)__builtin_ctzll(todo);
+        todo &= todo - 1;
+        const int base = chunk << 6;
         const int i = base + lane;
         double best = __builtin_inf();
         for (int jj = 0; jj < per; jj++) {
             const OppPair &o = pairs[jj];
-            if (o.hi < base || o.lo > base + 63) continue; // uniform: this chunk is outside the span
+            if (!((o.chunks >> chunk) & 1ull)) continue; // uniform: nothing of this opponent in this chunk
             if (i < o.lo || i > o.hi || i >= a.nb) continue;
             const double2 cs = a.beam_cs[i];
             const double v3x = o.cA * cs.x - o.sA * cs.y, v3y = o.sA * cs.x + o.cA * cs.y;
@@ -997,6 +1030,19 @@ __global__ __launch_bounds__(256) void opp_apply_kernel(OppArgs a)
             // from the ray's line.  Beyond the padded half diagonal no edge can be crossed (every get_range would
             // return inf), which is the case for ~95 % of the beams when the span is the whole scan.
             if (!(fabs(o.qx * v3x + o.qy * v3y) <= o.reach)) continue;
+            // The ray's direction is (v3y, -v3x).  If the whole bounding circle lies BEHIND the car along it, every edge
+            // point has a negative ray parameter: get_range rejects it (d1 >= 0, :271) -- unless an edge is exactly
+            // parallel to the ray (denom == 0: the collinear branch answers whatever the direction, :275-280).
+            if (o.qx * v3y - o.qy * v3x < -o.reach) {
+                bool parallel = false;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int en = (e + 1) & 3;
+                    const double denom = (o.v[2 * en] - o.v[2 * e]) * v3x + (o.v[2 * en + 1] - o.v[2 * e + 1]) * v3y;
+                    parallel = parallel || !(fabs(denom) > 0.0);
+                }
+                if (!parallel) continue;
+            }
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 const int en = (e + 1) & 3;
@@ -1029,13 +1075,46 @@ struct DynArgs {
     int integrator;
 };
 
+// The single-track model switches to its kinematic form below 0.5 m/s (dynamic_models.py:152): a wavefront that holds
+// one slow car among 63 fast ones executes BOTH forms at every RK4 stage (the slow form is a third of the instructions
+// of a step, and with autoreset a few per cent of the cars are always just leaving their spawn pose -- enough to put a
+// slow car into most wavefronts).  The block therefore deals its cars out so that the slow ones (and the idle lanes)
+// share the LAST wavefronts: lane l works on car s_perm[l], the others' waves skip the kinematic code altogether.
+// Which lane integrates a car does not change a bit of its result.
 __global__ __launch_bounds__(256) void dynamics_kernel(DynArgs a)
 {
-    const int car = blockIdx.x * blockDim.x + threadIdx.x;
-    if (car >= a.n_cars) return;
+    __shared__ int s_perm[256];
+    __shared__ int s_cnt[2][4]; // per wave: fast cars, slow cars
+    int car;
+    {
+        const int c0 = blockIdx.x * blockDim.x + threadIdx.x;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        bool work = c0 < a.n_cars, slow = true;
+        if (work) {
+            const bool pend0 = a.pending_reset && a.pending_reset[c0 / a.agents];
+            if (a.reset_only && !pend0) work = false;
+            else slow = pend0 || !(fabs(a.state[(size_t)c0 * 7 + 3]) >= 0.5); // a reset car starts at rest
+        }
+        const unsigned long long mf = __builtin_amdgcn_ballot_w64(work && !slow), ms = __builtin_amdgcn_ballot_w64(work && slow);
+        if (lane == 0) { s_cnt[0][wave] = __popcll(mf); s_cnt[1][wave] = __popcll(ms); }
+        for (int i = threadIdx.x; i < 256; i += blockDim.x) s_perm[i] = -1;
+        __syncthreads();
+        int fast_before = 0, slow_before = 0, fast_total = 0, slow_total = 0;
+        for (int w = 0; w < 4; w++) {
+            if (w < wave) { fast_before += s_cnt[0][w]; slow_before += s_cnt[1][w]; }
+            fast_total += s_cnt[0][w]; slow_total += s_cnt[1][w];
+        }
+        const unsigned long long below = (1ull << lane) - 1ull;
+        // fast cars fill the block's lanes from the front, slow cars from the back (idle lanes in between)
+        if (work && !slow) s_perm[fast_before + __popcll(mf & below)] = c0;
+        if (work && slow) s_perm[255 - (slow_before + __popcll(ms & below))] = c0;
+        __syncthreads();
+        car = s_perm[threadIdx.x];
+        (void)fast_total; (void)slow_total;
+    }
+    if (car < 0) return;
     const int env = car / a.agents;
     const bool pend = a.pending_reset && a.pending_reset[env];
-    if (a.reset_only && !pend) return;
     double st[7], sb[2];
     int sc;
     double steer, speed;

@@ -388,7 +388,9 @@ class Engine(object):
         return e.value
 
     # ------------------------------------------------------------------ measurement aid
-    def profile_begin(self, max_launches):
+    def profile_begin(self, max_launches, every=1):
+        """hipEvent pairs on the scan dispatch of every `every`-th step from now on (f110_profile_begin / _every)."""
+        _lib.check(self.lib.f110_profile_every(self._h, int(every)))
         _lib.check(self.lib.f110_profile_begin(self._h, int(max_launches)))
 
     def profile_end(self):
