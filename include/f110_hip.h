@@ -43,7 +43,7 @@ extern "C" {
 #define F110_E_INDEX (-4)    /* agent index out of range (base_classes.py:525-527) */
 #define F110_E_UNBOUND (-5)  /* step/reset before f110_bind */
 
-#define F110_MAX_AGENTS 8
+#define F110_MAX_AGENTS 32
 #define F110_MAX_MAPS 64  /* map slots of one handle (f110_set_map_slot_*, f110_assign_maps) */
 #define F110_NUM_PARAMS 18
 #define F110_RK4 1   /* Integrator.RK4   base_classes.py:40-42 */

@@ -618,7 +618,7 @@ int orc_collision_quads(const double *a, const double *b)
 /* ------------------------------------------------------------------------- */
 /* Simulator (base_classes.py:445-623) + F110Env lap logic (f110_env.py)       */
 /* ------------------------------------------------------------------------- */
-#define ORC_MAX_AGENTS 8
+#define ORC_MAX_AGENTS 32
 
 typedef struct {
     int num_agents, ego_idx, integrator;

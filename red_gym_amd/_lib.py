@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('F110_LIB') or os.path.join(_HERE, 'libf110_hip.so')  # F110_LIB: kernel-variant sweeps
 
-F110_MAX_AGENTS = 8
+F110_MAX_AGENTS = 32
 F110_NUM_PARAMS = 18
 F110_RK4, F110_EULER = 1, 2
 E_INVALID, E_HIP, E_NOMAP, E_INDEX, E_UNBOUND = -1, -2, -3, -4, -5

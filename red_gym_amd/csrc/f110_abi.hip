@@ -878,8 +878,26 @@ static bool parse_stage_spec(const char *p, std::vector<StageSpec> &spec, const 
     return true;
 }
 
+// Every pointer a scan launch dereferences without a test of its own, checked on the host: a null here is an error
+// code, on the device it is "Memory access fault ... on address (nil)" in every wave (round 2, gpurun_out/r02d).
+static int check_scan_args(const ScanArgs &a, const char *who)
+{
+    if (a.n_cars < 1 || a.agents < 1 || a.scan.nb < 2 || a.scan.nb > MAX_CHUNKS * 64) return fail(F110_E_INVALID, "%s: %d cars, %d agents, %d beams", who, a.n_cars, a.agents, a.scan.nb);
+    if (!a.maps || !a.scan.cs || a.scan.cs_len < a.scan.theta_dis || !a.chunk_beam0 || !a.pose_src) return fail(F110_E_INVALID, "%s: a table of the scan is missing (maps / {cos,sin} LUT / chunk order / poses)", who);
+    if (!a.out_f32 && !a.out_f64) return fail(F110_E_INVALID, "%s: no output buffer", who);
+    if (a.state && (!a.noise_step || !a.noise_side || a.noise_T < 1 || !a.beam_cosines || !a.in_collision || !a.pending_reset))
+        return fail(F110_E_INVALID, "%s: a buffer of the step's scan is missing (noise / beam cosines / in_collision / pending_reset)", who);
+    if (!a.state && a.reset_only) return fail(F110_E_INVALID, "%s: reset_only without the step's buffers", who);
+    if (a.f.state && (!a.f.noise_step || !a.f.spawn || !a.f.pending_reset || !a.f.in_collision || !a.f.collisions || !a.f.collision_idx ||
+                      !a.f.start_rot || !a.f.near_start || !a.f.toggles || !a.f.lap_counts || !a.f.lap_times || !a.f.current_time || !a.f.done))
+        return fail(F110_E_INVALID, "%s: a buffer of the closing form is missing", who);
+    return F110_OK;
+}
+
 static int launch_scan(f110_handle *h, const ScanArgs &a_in, const Sink &st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr)
 {
+    int rc_args = check_scan_args(a_in, "scan launch");
+    if (rc_args) return rc_args;
     ScanArgs a = a_in;
     a.wpc = waves_per_car(a.n_cars, a.scan.nb);
     // Drain of a launch: workgroups are dispatched in index order and nothing follows the last ones,
@@ -981,6 +999,7 @@ static int launch_group(f110_handle *h, const GroupArgs &a, int mode, int waves,
                         hipEvent_t ev1 = nullptr)
 {
     if (a.s.n_cars < 1 || waves < 1 || waves > GROUP_MAX_WAVES) return fail(F110_E_INVALID, "car-group launch: %d cars, %d waves per car", a.s.n_cars, waves);
+    if (int rc_args = check_scan_args(a.s, "car-group launch")) return rc_args;
     if (mode >= 2 && a.s.agents != 1) return fail(F110_E_INVALID, "the fused step needs num_agents == 1");
 #if defined(F110_TIMELINE)
     GroupArgs at = a;

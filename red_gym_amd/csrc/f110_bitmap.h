@@ -153,7 +153,39 @@ __device__ inline int bm_edge_setup(int mode, int rows, int cols, int2 p0, int2 
     return L + R;
 }
 
-__device__ inline void bm_set(unsigned *plane, int S, int x, int y) { atomicOr(&plane[y * S + (x >> 5)], 1u << (x & 31)); }
+// (row and pitch fit 24 bits: one full-rate v_mad_u32_u24 instead of a quarter-rate 32-bit multiply per pixel)
+// bm_edge_setup for a segment whose end points both lie inside the image (no clipLine, nothing past 32 bits but the
+// record's two 64-bit fields): the same record, bit for bit.
+__device__ inline int bm_edge_setup_inside(int mode, int2 p0, int2 p1, EdgeRec &r)
+{
+    int x1 = p0.x, y1 = p0.y, dx = p1.x - p0.x, dy = p1.y - p0.y;
+    if (dx < 0) { dx = -dx; dy = -dy; x1 = p1.x; y1 = p1.y; }      // leftToRight
+    unsigned neg = 0;
+    if (dy < 0) { dy = -dy; neg = 1; }
+    const unsigned vert = dy > dx;
+    const unsigned dmaj = vert ? dy : dx, dmin = vert ? dx : dy;
+    r.xy0 = (unsigned)x1 | (unsigned)y1 << 16;
+    r.lin = dmaj | dmin << 13 | neg << 26 | vert << 27 | 1u << 28;
+    r.rows = 0; r.mark = 0; r.x = 0; r.dx = 0;
+    const int L = (int)dmaj + 1;
+    int R = 0;
+    if (mode == BM_FILL && p0.y != p1.y) {
+        const int half = 1 << (BM_XY_SHIFT - 1);
+        const int c0x = (p0.x << BM_XY_SHIFT) + half, c1x = (p1.x << BM_XY_SHIFT) + half; // x < 4096: fits 32 bits
+        const int fdx = (int)((double)(c1x - c0x) / (double)(p1.y - p0.y)); // truncated toward zero, as the 64-bit form
+        const int ya = p0.y < p1.y ? p0.y : p1.y;
+        R = p0.y < p1.y ? p1.y - p0.y : p0.y - p1.y;
+        r.rows = (unsigned)ya | (unsigned)R << 16;
+        r.x = p0.y < p1.y ? c0x : c1x;
+        r.dx = fdx;
+    } else if (mode == BM_RAYS) {
+        R = 25; // the marker around an end point inside the image always touches it
+        r.mark = (int)((unsigned)(p1.x & 0xffff) | (unsigned)p1.y << 16);
+    }
+    return L + R;
+}
+
+__device__ inline void bm_set(unsigned *plane, int S, int x, int y) { atomicOr(&plane[__mul24(y, S) + (x >> 5)], 1u << (x & 31)); }
 
 // block-wide exclusive scan of one int per thread; returns the exclusive prefix, the sum in `total`
 __device__ inline int bm_block_scan(int v, int &total, int *s_wave)
@@ -247,25 +279,53 @@ __global__ __launch_bounds__(BM_THREADS) void bitmap_kernel(BitmapArgs a)
     const int img = blockIdx.x;
     const int cx = rows / 2, cy = cols / 2; // lidar.py:75: center = (dims[0]//2, dims[1]//2), used as (x, y)
 
-    for (int i = tid; i < rows * S; i += BM_THREADS) anyp[i] = 0u;
     // lidar.py:70-81: points = rint(center + (scaling_factor * data) * {cos, sin}(angles)).astype(int)
     for (int k = tid; k < T; k += BM_THREADS) pts[k] = bm_point(a, img, k, cx, cy);
     __syncthreads();
 
-    // ---- one record per segment: polygon edges pts[i-1] -> pts[i] (FILL, POLYGON) or rays centre -> pts[i]
+    // ---- one record per segment: polygon edges pts[i-1] -> pts[i] (FILL, POLYGON) or rays centre -> pts[i].
+    // Two passes: segments inside the image (most of them) take the short 32-bit set-up; the ones that need clipLine's
+    // 64-bit arithmetic and fp64 divisions are queued and set up afterwards by the first threads only -- in one pass every
+    // wave would run the long form for its few outside segments.  Item counts go through start[] (scanned below).
+    __shared__ int s_nout;
+    // the queue of outside segments (<= T ints) sits behind the points if the parity plane they are overlaid on has the
+    // room, else in the (not yet used) image plane; an image too small for either sets every segment up the long way
+    int *outq = par_words >= 3 * T ? reinterpret_cast<int *>(parp + 2 * T) : rows * S >= T ? reinterpret_cast<int *>(anyp) : nullptr;
+    if (tid == 0) s_nout = 0;
+    __syncthreads();
+    for (int i = tid; i < T; i += BM_THREADS) {
+        const int2 p1 = pts[i];
+        const int2 p0 = mode == BM_RAYS ? make_int2(cx, cy) : pts[i == 0 ? T - 1 : i - 1];
+        const bool outside = (unsigned)p0.x >= (unsigned)cols || (unsigned)p1.x >= (unsigned)cols ||
+                             (unsigned)p0.y >= (unsigned)rows || (unsigned)p1.y >= (unsigned)rows;
+        if (outside && outq) outq[atomicAdd(&s_nout, 1)] = i;
+        else if (outside) {
+            EdgeRec r;
+            start[i] = bm_edge_setup(mode, rows, cols, p0, p1, r);
+            recs[i] = r;
+        } else {
+            EdgeRec r;
+            start[i] = bm_edge_setup_inside(mode, p0, p1, r);
+            recs[i] = r;
+        }
+    }
+    __syncthreads();
+    for (int j = tid; j < s_nout; j += BM_THREADS) {
+        const int i = outq[j];
+        const int2 p1 = pts[i];
+        const int2 p0 = mode == BM_RAYS ? make_int2(cx, cy) : pts[i == 0 ? T - 1 : i - 1];
+        EdgeRec r;
+        start[i] = bm_edge_setup(mode, rows, cols, p0, p1, r);
+        recs[i] = r;
+    }
+    __syncthreads();
+    // exclusive prefix of the item counts, in place: thread t owns segments t*per .. t*per + per - 1
     const int per = (T + BM_THREADS - 1) / BM_THREADS;
     int cnt[BM_PER_MAX], local = 0;
 #pragma unroll
     for (int q = 0; q < BM_PER_MAX; q++) {
-        cnt[q] = 0;
         const int i = tid * per + q;
-        if (q < per && i < T) {
-            const int2 p1 = pts[i];
-            const int2 p0 = mode == BM_RAYS ? make_int2(cx, cy) : pts[i == 0 ? T - 1 : i - 1];
-            EdgeRec r;
-            cnt[q] = bm_edge_setup(mode, rows, cols, p0, p1, r);
-            recs[i] = r;
-        }
+        cnt[q] = (q < per && i < T) ? start[i] : 0;
         local += cnt[q];
     }
     int total;
@@ -276,6 +336,7 @@ __global__ __launch_bounds__(BM_THREADS) void bitmap_kernel(BitmapArgs a)
         if (q < per && i < T) { start[i] = base; base += cnt[q]; }
     }
     if (tid == 0) start[T] = total;
+    for (int i = tid; i < rows * S; i += BM_THREADS) anyp[i] = 0u;   // (held the queue of outside segments)
     for (int i = tid; i < par_words; i += BM_THREADS) parp[i] = 0u;   // every thread is past its pts reads (barrier in the scan)
     if (a.draw_center && mode != BM_FILL && tid < 25) {
         // lidar.py:98-100: centre marker in the draw colour (FILL clears it after the fill, below)
@@ -327,7 +388,7 @@ __global__ __launch_bounds__(BM_THREADS) void bitmap_kernel(BitmapArgs a)
                     xr += r.dx;
                     if (X < 0) atomicXor(&carry[y >> 5], 1u << (y & 31));
                     else if (X < cols) {
-                        atomicXor(&parp[y * S + (int)(X >> 5)], 1u << (X & 31));
+                        atomicXor(&parp[__mul24(y, S) + (int)(X >> 5)], 1u << (X & 31));
                         bm_set(anyp, S, (int)X, y);
                     }
                 } else {
@@ -370,18 +431,26 @@ __global__ __launch_bounds__(BM_THREADS) void bitmap_kernel(BitmapArgs a)
         if (ch == 4) {
             // 4 pixels -> 16 bytes "v v v 255" each (lidar.py:150-152: opaque alpha), lanes contiguous
             const int quads = rows * cols / 4, qpr = cols / 4;
+            // (y, h) of chunk c = tid + i * BM_THREADS advanced by carry, not divided out per chunk (a 32-bit division
+            // is ~25 instructions, three of them quarter-rate multiplies: a tenth of this kernel)
+            const int dq = BM_THREADS / qpr, dr = BM_THREADS - dq * qpr;
+            int y = tid / qpr, h = tid - y * qpr, yS = __mul24(y, S);
+            const int dqS = __mul24(dq, S);
             for (int c = tid; c < quads; c += BM_THREADS) {
-                const int y = c / qpr, h = c - y * qpr;
-                const unsigned e = bm_expand4((anyp[y * S + (h >> 3)] >> ((h & 7) * 4)) & 15u, cols2);
+                const unsigned e = bm_expand4((anyp[yS + (h >> 3)] >> ((h & 7) * 4)) & 15u, cols2);
                 bm_store16<true>(dst4 + c, __builtin_amdgcn_perm(0u, e, 0x0d000000u), __builtin_amdgcn_perm(0u, e, 0x0d010101u),
                                  __builtin_amdgcn_perm(0u, e, 0x0d020202u), __builtin_amdgcn_perm(0u, e, 0x0d030303u));
+                h += dr; y += dq; yS += dqS;
+                if (h >= qpr) { h -= qpr; y++; yS += S; }
             }
         } else {
             // 16 pixels (half a plane word) per step: 16 or 48 output bytes as 16-byte stores
             const int chunks = rows * cols / 16, cpr = cols / 16;
+            const int dq = BM_THREADS / cpr, dr = BM_THREADS - dq * cpr; // (see above)
+            int y = tid / cpr, h = tid - y * cpr, yS = __mul24(y, S);
+            const int dqS = __mul24(dq, S);
             for (int c = tid; c < chunks; c += BM_THREADS) {
-                const int y = c / cpr, h = c - y * cpr;
-                const unsigned bits = (anyp[y * S + (h >> 1)] >> ((h & 1) * 16)) & 0xffffu;
+                const unsigned bits = (anyp[yS + (h >> 1)] >> ((h & 1) * 16)) & 0xffffu;
                 unsigned e4[4];
 #pragma unroll
                 for (int q = 0; q < 4; q++) e4[q] = bm_expand4((bits >> (4 * q)) & 15u, cols2);
@@ -398,6 +467,8 @@ __global__ __launch_bounds__(BM_THREADS) void bitmap_kernel(BitmapArgs a)
 #pragma unroll
                     for (int q = 0; q < 3; q++) bm_store16<false>(dst4 + 3 * c + q, w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
                 }
+                h += dr; y += dq; yS += dqS;
+                if (h >= cpr) { h -= cpr; y++; yS += S; }
             }
         }
     } else {

@@ -30,6 +30,12 @@ def _mk_oracle_env(assets, A, noise_steps, integrator=oracle.RK4):
     return oracle.Env(sc, A, noise=oracle.noise_table(12345, noise_steps), integrator=integrator)
 
 
+def _mk_scanner(assets):
+    sc = oracle.Scanner(1080, 2 * np.pi)
+    sc.set_map(os.path.join(assets, 'example_map.yaml'), '.png')
+    return sc
+
+
 def _vec(assets, B, A, **kw):
     from red_gym_amd import F110VecEnv
     kw.setdefault('autoreset', False)
@@ -572,6 +578,45 @@ def test_step_paths_give_identical_results(assets, form, A):
     b64, b32, blk = e2.eng.scan(ps, want_f32=True, want_lookups=True)
     assert torch.equal(a64, b64) and torch.equal(a32, b32) and torch.equal(alk, blk)
     e1.close(); e2.close()
+
+
+def test_twelve_agents_vs_oracle(assets):
+    """The reference takes any num_agents (f110_env.py:131-134, base_classes.py:484-490); the handle takes up to
+    F110_MAX_AGENTS = 32.  12 cars per env in a queue on the raceline, 1 m apart (neighbours overlap in their scans and
+    some touch): 40 random steps against oracle envs -- state / scans 1e-9, collisions, collision_idx (last partner in
+    pair order), toggles and done `==`."""
+    B, A, T = 3, 12, 40
+    rl = np.loadtxt(os.path.join(assets, 'example_waypoints.csv'), delimiter=';', skiprows=3)
+    rng = np.random.default_rng(12)
+    poses = np.zeros((B, A, 3))
+    for b in range(B):
+        for a in range(A):
+            k = (200 * b + 300 - 5 * a) % rl.shape[0]
+            poses[b, a] = [rl[k, 1] + rng.normal(0, 0.05), rl[k, 2] + rng.normal(0, 0.05), rl[k, 3] + np.pi / 2]
+    poses[1, 5, :2] = poses[1, 4, :2] + 0.2   # two cars on top of each other: GJK hit from the start
+    env = _vec(assets, B, A, ego_idx=7)
+    ors = [oracle.Env(_mk_scanner(assets), A, noise=oracle.noise_table(12345, T + 2), ego_idx=7) for _ in range(B)]
+    env.reset(poses)
+    oo = [ors[b].reset(poses[b]) for b in range(B)]
+    hits = 0
+    for k in range(T):
+        act = np.stack([rng.uniform(-0.4189, 0.4189, (B, A)), rng.uniform(0, 6, (B, A))], axis=2)
+        obs, _, done, info = env.step(act)
+        oo = [ors[b].step(act[b]) for b in range(B)]
+        st = _np(env.state)
+        for b in range(B):
+            assert np.allclose(st[b], oo[b]['state'], rtol=0, atol=1e-9), (k, b)
+            assert np.allclose(_np(obs['scans_f64'])[b], oo[b]['scans'], rtol=0, atol=1e-9), (k, b)
+            assert np.array_equal(_np(obs['collisions'])[b].astype(np.float64), oo[b]['collisions']), (k, b)
+            assert np.array_equal(_np(info['collision_idx'])[b].astype(np.float64), oo[b]['collision_idx']), (k, b)
+            assert np.array_equal(_np(info['toggles'])[b].astype(np.float64), oo[b]['toggles']), (k, b)
+            assert bool(_np(done)[b]) == oo[b]['done'], (k, b)
+        hits += int(_np(obs['collisions']).sum())
+    assert hits > 0
+    from red_gym_amd import F110VecEnv
+    with pytest.raises(ValueError):
+        F110VecEnv(1, map=os.path.join(assets, 'example_map'), num_agents=33)
+    env.close()
 
 
 def test_set_scan_stages_refuses_malformed_lists(assets):
