@@ -130,7 +130,7 @@ def test_scan_empty_and_errors(eng):
     with pytest.raises(SyntaxError):
         Engine(num_envs=1, num_agents=1, integrator=7)
     with pytest.raises(ValueError):
-        Engine(num_envs=1, num_agents=9)
+        Engine(num_envs=1, num_agents=33)  # F110_MAX_AGENTS = 32
 
 
 @pytest.mark.parametrize('tag,integ', [('rk4', 1), ('euler', 2)])
