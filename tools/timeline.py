@@ -19,22 +19,29 @@ ap.add_argument('--envs', type=int, default=4096)
 ap.add_argument('--path', default='classic')
 ap.add_argument('--stages', default='')
 ap.add_argument('--warm', type=int, default=60)
+ap.add_argument('--agents', type=int, default=1)
 a = ap.parse_args()
 lib = _lib.load()
 lib.f110_debug_timeline.argtypes = [C.c_void_p, C.c_int64]
 B = a.envs
-env = F110VecEnv(B, map=workload.EXAMPLE_MAP, num_agents=1, autoreset=True)
+env = F110VecEnv(B, map=workload.EXAMPLE_MAP, num_agents=a.agents, autoreset=True, count_lookups=True)
 name, _, w = a.path.partition(':')
 env.eng.set_step_path(name, int(w or 0))
 if a.stages:
     env.eng.set_scan_stages(a.stages)
-env.reset(torch.as_tensor(workload.spawn_poses(B, 1), device=env.device))
-acts = torch.as_tensor(workload.action_pool(8, B, 1), device=env.device)
+env.reset(torch.as_tensor(workload.spawn_poses(B, a.agents), device=env.device))
+acts = torch.as_tensor(workload.action_pool(8, B, a.agents), device=env.device)
 for k in range(a.warm):
     env.step(acts[k % 8])
 torch.cuda.synchronize()
+env.eng.t['lookups'].zero_()
+env.step(acts[7])
+torch.cuda.synchronize()
+prev_lookups = env.eng.t['lookups'].clone().reshape(-1).cpu().numpy().astype(np.int64)  # the step before the stamped one
+env.eng.t['lookups'].zero_()
 env.step(acts[0])
 torch.cuda.synchronize()
+lookups = env.eng.t['lookups'].reshape(-1).cpu().numpy().astype(np.int64)
 N = 1 << 18
 buf = np.zeros((N, 4), dtype=np.uint64)
 assert lib.f110_debug_timeline(buf.ctypes.data_as(C.c_void_p), N) == 0
@@ -74,6 +81,18 @@ if group:
     print('  wave iterations per wave: ' + pc(it_end) + '   of them after the queue ran dry: ' + pc(drain_it))
     print('  us per iteration in the drain phase, all waves: ' + ' '.join('%.3f' % v for v in np.percentile((drain_us / np.maximum(drain_it, 1))[ok], [10, 50, 90])))
     print('  the 12 waves that end last: ' + '  '.join('end %.0f us: %d it, drain %d it @ %.3f us' % (end[i], it_end[i], drain_it[i], drain_us[i] / max(drain_it[i], 1)) for i in last))
+# the longest-living waves: does the car's lookup count (this step / the step before) predict them?
+life = end - start
+top = np.argsort(life)[-12:][::-1]
+rank_now = np.argsort(np.argsort(-lookups)); rank_prev = np.argsort(np.argsort(-prev_lookups))
+print('  longest-living waves: ' + '  '.join('%.0f us (start %.0f, %d w/car) car lookups %d = rank %d now, %d before' % (
+    life[i], start[i], wpc[i], lookups[car[i]], rank_now[car[i]], rank_prev[car[i]]) for i in top))
+w1 = wpc == 1
+if w1.sum() > 100:
+    cc = np.corrcoef(life[w1], lookups[car[w1]])[0, 1]
+    cp = np.corrcoef(life[w1], prev_lookups[car[w1]])[0, 1]
+    print('  whole-car waves: correlation of lifetime with the car\'s lookups %.3f (this step), %.3f (previous step); lookups per car p50/p99/max %d %d %d'
+          % (cc, cp, np.percentile(lookups, 50), np.percentile(lookups, 99), lookups.max()))
 grid = np.arange(0.0, end.max() + 5.0, 5.0)
 res = [(int(((start <= t) & (end > t)).sum())) for t in grid]
 print('  resident waves every 5 us: ' + ' '.join(str(r) for r in res))
