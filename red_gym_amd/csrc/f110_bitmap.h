@@ -336,8 +336,20 @@ __global__ __launch_bounds__(BM_THREADS) void bitmap_kernel(BitmapArgs a)
         if (q < per && i < T) { start[i] = base; base += cnt[q]; }
     }
     if (tid == 0) start[T] = total;
-    for (int i = tid; i < rows * S; i += BM_THREADS) anyp[i] = 0u;   // (held the queue of outside segments)
-    for (int i = tid; i < par_words; i += BM_THREADS) parp[i] = 0u;   // every thread is past its pts reads (barrier in the scan)
+    // zero both planes (anyp held the queue of outside segments; every thread is past its pts reads: barrier in the scan)
+    // -- 16 bytes per store where the plane starts on a 16-byte boundary (the records before it are 32 bytes each)
+    {
+        uint4 *z4 = reinterpret_cast<uint4 *>(parp);
+        const int n4 = par_words >> 2;
+        for (int i = tid; i < n4; i += BM_THREADS) z4[i] = make_uint4(0u, 0u, 0u, 0u);
+        for (int i = (n4 << 2) + tid; i < par_words; i += BM_THREADS) parp[i] = 0u;
+        const int nw = rows * S, head = (int)(((16u - ((unsigned)(size_t)anyp & 15u)) & 15u) >> 2); // words up to the next boundary
+        for (int i = tid; i < min(head, nw); i += BM_THREADS) anyp[i] = 0u;
+        uint4 *a4 = reinterpret_cast<uint4 *>(anyp + head);
+        const int m4 = nw > head ? (nw - head) >> 2 : 0;
+        for (int i = tid; i < m4; i += BM_THREADS) a4[i] = make_uint4(0u, 0u, 0u, 0u);
+        for (int i = head + (m4 << 2) + tid; i < nw; i += BM_THREADS) anyp[i] = 0u;
+    }
     if (a.draw_center && mode != BM_FILL && tid < 25) {
         // lidar.py:98-100: centre marker in the draw colour (FILL clears it after the fill, below)
         const int x = cx - 2 + tid % 5, y = cy - 2 + tid / 5;
@@ -401,6 +413,15 @@ __global__ __launch_bounds__(BM_THREADS) void bitmap_kernel(BitmapArgs a)
     }
     __syncthreads();
 
+    const int ch = a.channels;
+    const size_t img_bytes = (size_t)rows * cols * ch;
+    unsigned char *dst = a.out + (size_t)img * img_bytes;
+    const unsigned cols2 = ((unsigned)a.bg & 255u) | ((unsigned)a.draw & 255u) << 8;
+    const bool use_tab = ch == 1 && (cols & 15) == 0 && (size_t)T * sizeof(EdgeRec) >= 256 * 8;
+    uint2 *tab = reinterpret_cast<uint2 *>(recs); // (the records are dead from here on)
+    if (use_tab && tid < 256) tab[tid] = make_uint2(bm_expand4((unsigned)tid & 15u, cols2), bm_expand4((unsigned)tid >> 4, cols2));
+    if (use_tab && mode != BM_FILL) __syncthreads(); // (FILL: the barrier behind the parity pass)
+
     if (mode == BM_FILL) {
         // ---- inside = crossing on the pixel, or an odd number of crossings strictly left of it; then the centre marker
         for (int y = tid; y < rows; y += BM_THREADS) {
@@ -422,11 +443,23 @@ __global__ __launch_bounds__(BM_THREADS) void bitmap_kernel(BitmapArgs a)
     }
 
     // ---- stream the image out: grey levels and channels are expanded here (the only HBM write)
-    const int ch = a.channels;
-    const size_t img_bytes = (size_t)rows * cols * ch;
-    unsigned char *dst = a.out + (size_t)img * img_bytes;
-    const unsigned cols2 = ((unsigned)a.bg & 255u) | ((unsigned)a.draw & 255u) << 8;
-    if ((cols & 15) == 0) {
+    // One channel: 8 pixel bits -> 8 grey bytes through a 256-entry table (2 KB, in the segment records' place: they are
+    // dead after the walk), built by the first 256 threads.  Two ds_read_b64 per 16-byte store replace the twelve VALU
+    // instructions of four bm_expand4 -- this kernel is bound by VALU issue (84 % busy), the LDS pipe has room.
+    if (use_tab) {
+        uint4 *dst4 = reinterpret_cast<uint4 *>(dst);
+        const int chunks = rows * cols / 16, cpr = cols / 16;
+        const int dq = BM_THREADS / cpr, dr = BM_THREADS - dq * cpr; // (y, h) advanced by carry: see below
+        int y = tid / cpr, h = tid - y * cpr, yS = __mul24(y, S);
+        const int dqS = __mul24(dq, S);
+        for (int c = tid; c < chunks; c += BM_THREADS) {
+            const unsigned bits = anyp[yS + (h >> 1)] >> ((h & 1) * 16);
+            const uint2 lo = tab[bits & 0xffu], hi = tab[(bits >> 8) & 0xffu];
+            bm_store16<true>(dst4 + c, lo.x, lo.y, hi.x, hi.y);
+            h += dr; y += dq; yS += dqS;
+            if (h >= cpr) { h -= cpr; y++; yS += S; }
+        }
+    } else if ((cols & 15) == 0) {
         uint4 *dst4 = reinterpret_cast<uint4 *>(dst);
         if (ch == 4) {
             // 4 pixels -> 16 bytes "v v v 255" each (lidar.py:150-152: opaque alpha), lanes contiguous
