@@ -296,6 +296,39 @@ def test_hipgraph_replay_equals_eager(assets):
     e1.close(); e2.close()
 
 
+@pytest.mark.parametrize('how', ['nodes', 'capture'])
+@pytest.mark.parametrize('A', [1, 2])
+def test_library_graph_replay_equals_eager(assets, how, A):
+    """f110_graph_create builds the step as a HIP graph itself (explicit kernel nodes / a private stream capture):
+    replays give the bits of eager steps, the node count is the step's launch count, a change of the handle's launch
+    epoch makes f110_graph_launch refuse the stale graph (F110_E_INVALID) and step_lib_graph re-build it."""
+    import ctypes as C
+    import torch
+    from red_gym_amd import _lib, workload
+    B = 128
+    poses = workload.spawn_poses(B, A)
+    acts = torch.as_tensor(workload.action_pool(8, B, A), device='cuda')
+    e1, e2 = _vec(assets, B, A, autoreset=True), _vec(assets, B, A, autoreset=True)
+    e1.reset(poses); e2.reset(poses)
+    buf = e2.build_step_graph(how)
+    n_nodes = e2.lib_graph_info()
+    assert 2 <= n_nodes <= 5
+    keys = [k for k in e1.eng.t if e1.eng.t[k] is not None]
+    for k in range(40):
+        e1.step(acts[k % 8])
+        buf.copy_(acts[k % 8])
+        e2.step_lib_graph()
+        if k == 20:
+            e2.eng.set_scan_stages('*:1')          # bumps the launch epoch
+            with pytest.raises(ValueError, match='stale'):
+                _lib.check(e2.eng.lib.f110_graph_launch(e2._lg, e2.eng._stream()))
+            e1.eng.set_scan_stages('*:1')
+    torch.cuda.synchronize()
+    for key in keys:
+        assert torch.equal(e1.eng.t[key], e2.eng.t[key]), key
+    e1.close(); e2.close()
+
+
 def test_hipgraph_survives_table_changes(assets):
     """A captured step freezes the noise table's address / length, the scan instantiation and the env -> map
     table.  The noise table is re-allocated when a car outlives it (here: 8 rows), and update_map can switch
