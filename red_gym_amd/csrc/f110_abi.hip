@@ -1000,14 +1000,15 @@ static int launch_group(f110_handle *h, const GroupArgs &a, int mode, int waves,
 {
     if (a.s.n_cars < 1 || waves < 1 || waves > GROUP_MAX_WAVES) return fail(F110_E_INVALID, "car-group launch: %d cars, %d waves per car", a.s.n_cars, waves);
     if (int rc_args = check_scan_args(a.s, "car-group launch")) return rc_args;
-    if (mode >= 2 && a.s.agents != 1) return fail(F110_E_INVALID, "the fused step needs num_agents == 1");
+    if (mode != 0 && mode != 1 && mode != 3) return fail(F110_E_INVALID, "car-group launch: mode %d", mode);
+    if (mode == 3 && a.s.agents != 1) return fail(F110_E_INVALID, "the closing car groups need num_agents == 1");
 #if defined(F110_TIMELINE)
     GroupArgs at = a;
     at.s.timeline = timeline_buffer();
-    return mode == 3 ? launch_group_t<3>(h, at, waves, st, ev0, ev1) : mode == 2 ? launch_group_t<2>(h, at, waves, st, ev0, ev1)
+    return mode == 3 ? launch_group_t<3>(h, at, waves, st, ev0, ev1)
          : mode == 1 ? launch_group_t<1>(h, at, waves, st, ev0, ev1) : launch_group_t<0>(h, at, waves, st, ev0, ev1);
 #endif
-    return mode == 3 ? launch_group_t<3>(h, a, waves, st, ev0, ev1) : mode == 2 ? launch_group_t<2>(h, a, waves, st, ev0, ev1)
+    return mode == 3 ? launch_group_t<3>(h, a, waves, st, ev0, ev1)
          : mode == 1 ? launch_group_t<1>(h, a, waves, st, ev0, ev1) : launch_group_t<0>(h, a, waves, st, ev0, ev1);
 }
 
@@ -1069,11 +1070,10 @@ static int run_step(f110_handle *h, const double *actions, int reset_only, const
     const bool prof = h->prof_on && !st.record && (h->prof_seq++ % h->prof_every) == 0 && (size_t)(2 * h->prof_n + 1) < h->prof_ev.size();
     hipEvent_t ev0 = prof ? h->prof_ev[2 * h->prof_n] : nullptr, ev1 = prof ? h->prof_ev[2 * h->prof_n + 1] : nullptr;
     static const bool nofuse = getenv("F110_GROUP_NOFUSE") != nullptr;     // sweeps: car groups for the scan only
-    static const bool fuse_dyn = getenv("F110_GROUP_FUSE_DYN") != nullptr; // sweeps: update_pose inside the group kernel, per car
     const bool closing = c.num_agents == 1 && (form == FORM_CLOSED || (form == FORM_GROUP && !nofuse));
     int rc;
 
-    if (!(form == FORM_GROUP && closing && fuse_dyn)) {
+    {
         DynArgs d;
         d.n_cars = N; d.agents = c.num_agents; d.state = b.state; d.steer_buf = b.steer_buf; d.steer_cnt = b.steer_cnt;
         d.noise_step = b.noise_step; d.actions = actions; d.spawn = b.spawn; d.pending_reset = b.pending_reset;
@@ -1089,7 +1089,7 @@ static int run_step(f110_handle *h, const double *actions, int reset_only, const
         fill_scan_args(h, g.s, reset_only);
         g.order = h->d_order;
         if (closing) fill_fuse_args(h, g.s.f, actions);
-        rc = launch_group(h, g, closing ? (fuse_dyn ? 2 : 3) : 1, gw, st, ev0, ev1);
+        rc = launch_group(h, g, closing ? 3 : 1, gw, st, ev0, ev1);
     } else {
         ScanArgs s;
         memset(&s, 0, sizeof(s));

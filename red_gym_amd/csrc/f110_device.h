@@ -150,54 +150,6 @@ __device__ inline void update_pose(double st[7], double sbuf[2], int &scnt, doub
     else if (st[4] < 0) st[4] = st[4] + 2 * F110_PI;
 }
 
-// The same update with a small register footprint, for a kernel whose occupancy is set by another loop (the fused
-// step of car_group_kernel: 64 VGPRs): the RK4 stages run as a ROLLED loop, and the two vectors that are only touched
-// between stages -- the state at the start of the step and the running sum of the slopes -- live in LDS (`w`, 14
-// doubles, one wave).  Bit for bit update_pose: the stage state is st + dt*(k*m) with m = 1/2, 1/2, 1 (k*0.5 == k/2
-// and k*1 == k exactly), and the sum is built in the reference's order ((k1 + 2*k2) + 2*k3) + k4
-// (base_classes.py:282-371).
-__device__ inline void update_pose_compact(double st[7], double sbuf[2], int &scnt, double raw_steer, double vel,
-                                           const Params &P, double time_step, int integrator, volatile double *w)
-{
-    double steer = 0.;
-    if (scnt < 2) {
-        sbuf[1] = sbuf[0];
-        sbuf[0] = raw_steer;
-        scnt++;
-    } else {
-        steer = sbuf[1];
-        sbuf[1] = sbuf[0];
-        sbuf[0] = raw_steer;
-    }
-    double accl, sv;
-    pid(vel, steer, st[3], st[2], P.v[P_SVMAX], P.v[P_AMAX], P.v[P_VMAX], P.v[P_VMIN], accl, sv);
-    double k[7];
-    if (integrator == 1) {
-#pragma unroll
-        for (int i = 0; i < 7; i++) w[i] = st[i];
-#pragma clang loop unroll(disable)
-        for (int j = 0; j < 4; j++) {
-            vehicle_dynamics_st(st, sv, accl, P, k);
-            const double m = j < 2 ? 0.5 : 1.0;
-#pragma unroll
-            for (int i = 0; i < 7; i++) {
-                if (j == 0) w[7 + i] = k[i];
-                else w[7 + i] = w[7 + i] + (j < 3 ? 2 * k[i] : k[i]);
-                st[i] = w[i] + time_step * (k[i] * m); // (the value after the last stage is not used)
-            }
-        }
-        const double wt = time_step * (1. / 6);
-#pragma unroll
-        for (int i = 0; i < 7; i++) st[i] = w[i] + wt * w[7 + i];
-    } else {
-        vehicle_dynamics_st(st, sv, accl, P, k);
-#pragma unroll
-        for (int i = 0; i < 7; i++) st[i] = st[i] + time_step * k[i];
-    }
-    if (st[4] > 2 * F110_PI) st[4] = st[4] - 2 * F110_PI;
-    else if (st[4] < 0) st[4] = st[4] + 2 * F110_PI;
-}
-
 // ---------------------------------------------------------------- collision
 // collision_models.py:219-260, vertex order rl, rr, fr, fl (:259)
 __device__ inline void get_vertices(double x, double y, double th, double length, double width,

@@ -516,12 +516,12 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
 // step.  Here ONE WORKGROUP of 2..8 wavefronts serves one car:
 //   * its waves draw beams from ONE queue (an LDS counter: `ds_add_rtn` per refill), so they finish together
 //     whatever the car's mix of long and short rays -- no static slices, no slice whose rays happen to be long;
-//   * MODE 2 (A == 1) is the WHOLE env step in one launch: wave 0 integrates the car (RaceCar.update_pose: steer
-//     FIFO, PID, RK4, yaw wrap -- or the reset + zero action of F110Env.reset) from the OLD state while the other waves
-//     stage the distance LUT, and hands the new state over through LDS; the last wave of the group to finish its rays
-//     (LDS arrival counter, which also carries the iTTC hits) writes the state back -- nobody in the group reads the
-//     old state after the barrier, no other group ever reads it -- and does the env bookkeeping of env_kernel
-//     (collision flags, iTTC zeroing, noise row, lap logic, done, autoreset).  No GJK at A == 1.
+//   * MODE 3 (A == 1) also closes the step: the last wave of the group to finish its rays (LDS arrival counter, which
+//     also carries the iTTC hits) does the env bookkeeping of env_kernel for its car (collision flags, iTTC zeroing,
+//     noise row, lap logic, done, autoreset).  No GJK at A == 1.  (A MODE 2 that also integrated the car -- wave 0 running
+//     update_pose while the others staged the LUT, the whole step in ONE launch -- was built, held to == and dropped:
+//     update_pose wants 144 VGPRs, under this kernel's 64 it spilled 160-260 registers to scratch, and one pass per CAR
+//     replaced 64 lane-parallel ones: 0.200 against 0.117 ms at 4 096 envs; tools/variants/fused_step_mode2.patch.)
 // Results are those of dynamics_kernel -> scan_kernel -> env_kernel bit for bit: a beam's value does not depend on
 // the lane that marched it, and the device functions are shared.
 constexpr int GROUP_MAX_WAVES = 8;
@@ -591,30 +591,20 @@ struct GroupArgs {
 static_assert(__is_trivially_copyable(GroupArgs) && offsetof(GroupArgs, s) == 0 && sizeof(GroupArgs) <= 4096,
               "car_group_kernel re-reads its only argument through the kernarg segment pointer");
 
-// a wave-uniform double held in VGPRs -> SGPRs
-__device__ inline double uniform_f64(double v)
-{
-    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
-    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
-    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
-}
-
-// MODE 0: ScanSimulator2D.scan(pose, None); 1: the scan of a step (noise, iTTC flag); 2: the whole step (A == 1);
-// 3: scan + env bookkeeping of a step whose dynamics_kernel has run (A == 1)
+// MODE 0: ScanSimulator2D.scan(pose, None); 1: the scan of a step (noise, iTTC flag); 3: scan + env bookkeeping of a
+// step whose dynamics_kernel has run (A == 1)
 template <bool IDENT, bool POW2, int MODE>
 #ifndef F110_GROUP_MIN_WAVES
 #define F110_GROUP_MIN_WAVES 8
 #endif
 __global__ __launch_bounds__(GROUP_MAX_WAVES * WAVE, F110_GROUP_MIN_WAVES) void car_group_kernel(GroupArgs a)
 {
-    constexpr bool STEP = MODE >= 1, FUSED = MODE == 2, CLOSE = MODE >= 2; // CLOSE: the last wave does env_kernel's work
+    static_assert(MODE == 0 || MODE == 1 || MODE == 3, "car_group_kernel modes");
+    constexpr bool STEP = MODE >= 1, CLOSE = MODE == 3; // CLOSE: the last wave does env_kernel's work
     __shared__ __attribute__((aligned(16))) double s_lut[LUT_LDS];
     __shared__ int s_chunk0[MAX_CHUNKS];
     __shared__ unsigned s_next;     // head of the car's beam queue
     __shared__ unsigned s_arrive;   // waves that have finished their rays (+ 0x10000 per wave with an iTTC hit)
-    __shared__ double s_car[12];    // FUSED: new state [7], steer FIFO [2], FIFO count, noise row
-    __shared__ double s_rk[FUSED ? 14 : 1]; // FUSED: update_pose_compact's between-stage vectors
     __shared__ unsigned s_cmax[MAX_CHUNKS]; // longest ray life (wave iterations) seen in each chunk of this scan
 #if defined(__HIP_DEVICE_COMPILE__)
     const GroupArgs *rare = (const GroupArgs *)__builtin_amdgcn_kernarg_segment_ptr();
@@ -653,54 +643,17 @@ __global__ __launch_bounds__(GROUP_MAX_WAVES * WAVE, F110_GROUP_MIN_WAVES) void 
 #if defined(F110_TIMELINE)
     { unsigned long long t = wall_clock64(); asm volatile("" : "+v"(t)); if (lane == 0) s_tl[wave][0] = t; }
 #endif
-    if (FUSED && wave == 0) {
-        // RaceCar.update_pose (base_classes.py:254-402) from the OLD state, or RaceCar.reset (:181-202) followed by
-        // the zero-action step of F110Env.reset (f110_env.py:335-336): what dynamics_kernel does for this car
-        const FuseArgs *F = &rare->s.f;
-        asm volatile("" : "+s"(F));
-        double st[7], sb[2], steer, speed;
-        int sc, row;
-        if (pend) {
-#pragma unroll
-            for (int i = 0; i < 7; i++) st[i] = 0.;
-            st[0] = F->spawn[(size_t)car * 3];
-            st[1] = F->spawn[(size_t)car * 3 + 1];
-            st[4] = F->spawn[(size_t)car * 3 + 2];
-            sb[0] = sb[1] = 0.;
-            sc = 0; steer = 0.; speed = 0.; row = 0;
-        } else {
-#pragma unroll
-            for (int i = 0; i < 7; i++) st[i] = F->state[(size_t)car * 7 + i];
-            sb[0] = F->steer_buf[(size_t)car * 2];
-            sb[1] = F->steer_buf[(size_t)car * 2 + 1];
-            sc = F->steer_cnt[car];
-            steer = F->actions[(size_t)car * 2];
-            speed = F->actions[(size_t)car * 2 + 1];
-            row = F->noise_step[car];
-        }
-        update_pose_compact(st, sb, sc, steer, speed, F->agent_params[0], F->time_step, F->integrator, s_rk);
-        if (lane == 0) {
-#pragma unroll
-            for (int i = 0; i < 7; i++) s_car[i] = st[i];
-            s_car[7] = sb[0]; s_car[8] = sb[1]; s_car[9] = (double)sc; s_car[10] = (double)row;
-        }
-    }
     __syncthreads();
     MapView mv;
     mv.cells_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(md.cells), 0, (int)md.cells_bytes, 0x00020000);
     mv.init(md);
 
-    double px, py, yaw, vel = 0.0;
+    double vel = 0.0;
     int row = 0;
-    if (FUSED) {
-        px = uniform_f64(s_car[0]); py = uniform_f64(s_car[1]); yaw = uniform_f64(s_car[4]); vel = uniform_f64(s_car[3]);
-        row = __builtin_amdgcn_readfirstlane((int)s_car[10]);
-    } else {
-        px = a.s.pose_src[(size_t)car * a.s.pose_stride];
-        py = a.s.pose_src[(size_t)car * a.s.pose_stride + 1];
-        yaw = a.s.pose_src[(size_t)car * a.s.pose_stride + a.s.yaw_off];
-        if (STEP) { vel = a.s.state[(size_t)car * 7 + 3]; row = a.s.noise_step[car]; }
-    }
+    const double px = a.s.pose_src[(size_t)car * a.s.pose_stride];
+    const double py = a.s.pose_src[(size_t)car * a.s.pose_stride + 1];
+    const double yaw = a.s.pose_src[(size_t)car * a.s.pose_stride + a.s.yaw_off];
+    if (STEP) { vel = a.s.state[(size_t)car * 7 + 3]; row = a.s.noise_step[car]; }
     const double eps = a.s.scan.eps, max_range = a.s.scan.max_range;
     const bool do_ttc = STEP && vel != 0.0;               // laser_models.py:206
     const double cand = a.s.ttc_thresh * fabs(vel) * 1.000000001; // see scan_kernel
@@ -871,22 +824,11 @@ __global__ __launch_bounds__(GROUP_MAX_WAVES * WAVE, F110_GROUP_MIN_WAVES) void 
     const bool anyhit = whit || (old >> 16) != 0u;
     const FuseArgs *F = &ra->s.f;
     double st[7];
-    if (FUSED) {
+    // dynamics_kernel has written the new state, the FIFO and the pose snapshot, and zeroed noise_step of a pending
+    // env; nobody in this launch but this lane touches the car's state from here on
 #pragma unroll
-        for (int i = 0; i < 7; i++) st[i] = s_car[i];
-        F->pose_snap[(size_t)car * 3] = st[0];       // poses after integration, before iTTC zeroing (base_classes.py:567)
-        F->pose_snap[(size_t)car * 3 + 1] = st[1];
-        F->pose_snap[(size_t)car * 3 + 2] = st[4];
-        F->steer_buf[(size_t)car * 2] = s_car[7];
-        F->steer_buf[(size_t)car * 2 + 1] = s_car[8];
-        F->steer_cnt[car] = (int)s_car[9];
-    } else {
-        // MODE 3: dynamics_kernel has written the new state, the FIFO and the pose snapshot, and zeroed noise_step of
-        // a pending env; nobody in this launch but this lane touches the car's state from here on
-#pragma unroll
-        for (int i = 0; i < 7; i++) st[i] = F->state[(size_t)car * 7 + i];
-    }
-    close_car_step(F, car, pend, anyhit, row, st, FUSED);
+    for (int i = 0; i < 7; i++) st[i] = F->state[(size_t)car * 7 + i];
+    close_car_step(F, car, pend, anyhit, row, st, false);
 }
 
 // ------------------------------------------------------------------ opponents (A > 1)
