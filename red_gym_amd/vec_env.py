@@ -229,7 +229,9 @@ class F110VecEnv(object):
         """Pure-pursuit actions when blocks of envs drive on different tracks (randomize_tracks): waypoint_sets[k]
         is the raceline [M_k,3] = (x, y, speed) of slot k, assign the int array [num_envs] of slots.  One planner
         launch for all of them (the packed racelines are cached while the same objects are passed)."""
-        key = (id(waypoint_sets), len(waypoint_sets), np.asarray(assign).tobytes())
+        # (the packed form is rebuilt when another list, other raceline objects or another assignment is passed; a raceline
+        # edited IN PLACE is not noticed -- build a new TrackSet with raceline_slots for that)
+        key = (tuple((id(w), tuple(getattr(w, 'shape', ()))) for w in waypoint_sets), np.asarray(assign).tobytes())
         if getattr(self, '_pp_tracks_key', None) != key:
             self._pp_tracks = self.raceline_slots(waypoint_sets, assign)
             self._pp_tracks_key = key
