@@ -84,7 +84,8 @@ struct f110_handle {
     double theta_inc = 0;
     // measurement aid (f110_profile_begin/end)
     std::vector<hipEvent_t> prof_ev; // pairs: [2*i] before, [2*i+1] after the scan launch
-    int prof_n = 0, prof_every = 1, prof_seq = 0; // events ride on every prof_every-th step's scan launch
+    int prof_n = 0, prof_every = 1, prof_seq = 0; // events ride on every prof_every-th step's scan launch (the middle one of
+                                                  // each run of prof_every steps: on a clock ramp the samples' mean is then the steps' mean)
     bool prof_on = false;
 };
 
@@ -1067,7 +1068,7 @@ static int run_step(f110_handle *h, const double *actions, int reset_only, const
     const int N = c.num_envs * c.num_agents;
     int gw = 0;
     const StepForm form = step_form(h, N, &gw);
-    const bool prof = h->prof_on && !st.record && (h->prof_seq++ % h->prof_every) == 0 && (size_t)(2 * h->prof_n + 1) < h->prof_ev.size();
+    const bool prof = h->prof_on && !st.record && (h->prof_seq++ % h->prof_every) == h->prof_every / 2 && (size_t)(2 * h->prof_n + 1) < h->prof_ev.size();
     hipEvent_t ev0 = prof ? h->prof_ev[2 * h->prof_n] : nullptr, ev1 = prof ? h->prof_ev[2 * h->prof_n + 1] : nullptr;
     static const bool nofuse = getenv("F110_GROUP_NOFUSE") != nullptr;     // sweeps: car groups for the scan only
     const bool closing = c.num_agents == 1 && (form == FORM_CLOSED || (form == FORM_GROUP && !nofuse));
