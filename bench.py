@@ -276,10 +276,12 @@ def main(argv=None):
                          % (args.gpus, world, world))
 
     B, A, K, W = args.envs, args.agents, args.steps, args.warmup
+    POOL = 16
+    # host-side preparation first (~0.1 s of NumPy), so that everything the GPU does before the timed region -- map
+    # pipeline, uploads, reset, warm-up -- follows back to back instead of being separated from it by an idle stretch
+    poses_np, acts_np = rank_workload(rank, B, A, POOL)
     env = F110VecEnv(B, map=workload.EXAMPLE_MAP, map_ext='.png', num_agents=A, timestep=0.01, seed=12345,
                      device=local_rank, autoreset=True, count_lookups=True)
-    POOL = 16
-    poses_np, acts_np = rank_workload(rank, B, A, POOL)
     poses = torch.as_tensor(poses_np, device=dev)
     acts = torch.as_tensor(acts_np, device=dev)  # resident in HBM before the timed region
     # The first ~30 steps after an idle period run up to 15 % slower (0.80 -> 0.69 ms) whatever the env state
