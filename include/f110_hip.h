@@ -141,8 +141,9 @@ int f110_track_mask(const double *pts_dev, int32_t n_pts, int32_t closed, int32_
  * (f110_env.py:100-157 takes `map` per env).  Slot 0 is the map of the calls above; f110_set_map_slot_* fill
  * slots 0..F110_MAX_MAPS-1 the same way, and f110_assign_maps gives every env its slot (host int32 [num_envs],
  * NULL = all envs on slot 0).  The cars of one scan workgroup (2 consecutive cars) must share a map, i.e.
- * assign maps to blocks of envs with an even car count; all slots in use should agree on "resolution is a
- * power of two" and "origin unrotated", otherwise the general (slower) scan instantiation runs for all. */
+ * assign maps to blocks of envs with an even car count.  Maps of different kinds ("resolution is a power of two",
+ * "origin unrotated") may be mixed: the shard is then scanned block by block, each run of envs with the instantiation
+ * its own maps allow (one more launch per change of kind along the env index). */
 int f110_set_map_slot_occupancy(f110_handle *h, int32_t slot, const uint8_t *free_mask_host, int32_t height, int32_t width,
                                 double resolution, double orig_x, double orig_y, double orig_c, double orig_s);
 int f110_set_map_slot_occupancy_dev(f110_handle *h, int32_t slot, const uint8_t *free_mask_dev, int32_t height,

@@ -796,8 +796,11 @@ static ScanDev scan_dev(const f110_handle *h)
 
 // ev0 / ev1 (measurement aid, may be null): start / stop events attached to the dispatch itself, which costs
 // less than bracketing the launch with two hipEventRecord calls (those add two barrier packets to the queue)
+// which scan instantiation a launch may use: origin unrotated / resolution a power of two for EVERY map its cars touch
+struct MapKind { bool ident, pow2; };
+
 template <int SM>
-static int launch_scan_t(f110_handle *h, const ScanArgs &a, const Sink &k, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr)
+static int launch_scan_t(MapKind kind, const ScanArgs &a, const Sink &k, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr)
 {
     int waves = 0;
     for (int i = 0; i < a.n_stages; i++) waves += a.stage_cars[i] << a.stage_log2w[i];
@@ -805,9 +808,9 @@ static int launch_scan_t(f110_handle *h, const ScanArgs &a, const Sink &k, hipEv
     // sweeps only: F110_SCAN_PAD_LDS=<bytes> of unused dynamic LDS per workgroup caps the workgroups per CU (160 KiB / (8.6 KiB + pad)),
     // i.e. emulates a lower occupancy without touching the kernel
     static const unsigned pad_lds = getenv("F110_SCAN_PAD_LDS") ? (unsigned)atoi(getenv("F110_SCAN_PAD_LDS")) : 0u;
-    const void *f = h->ident && h->pow2 ? (const void *)&scan_kernel<true, true, SM>
-                  : h->ident            ? (const void *)&scan_kernel<true, false, SM>
-                  : h->pow2             ? (const void *)&scan_kernel<false, true, SM>
+    const void *f = kind.ident && kind.pow2 ? (const void *)&scan_kernel<true, true, SM>
+                  : kind.ident              ? (const void *)&scan_kernel<true, false, SM>
+                  : kind.pow2               ? (const void *)&scan_kernel<false, true, SM>
                                         : (const void *)&scan_kernel<false, false, SM>;
     return emit(k, f, grid, block, pad_lds, a, ev0, ev1);
 }
@@ -895,8 +898,10 @@ static int check_scan_args(const ScanArgs &a, const char *who)
     return F110_OK;
 }
 
-static int launch_scan(f110_handle *h, const ScanArgs &a_in, const Sink &st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr)
+static int launch_scan(f110_handle *h, const ScanArgs &a_in, const Sink &st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr,
+                       const MapKind *kind_or_null = nullptr)
 {
+    const MapKind kind = kind_or_null ? *kind_or_null : MapKind{h->ident, h->pow2};
     int rc_args = check_scan_args(a_in, "scan launch");
     if (rc_args) return rc_args;
     ScanArgs a = a_in;
@@ -961,9 +966,9 @@ static int launch_scan(f110_handle *h, const ScanArgs &a_in, const Sink &st, hip
     if (a.f.state) { // the closing form (one agent): the arrival counters of split cars
         if (a.agents != 1 || !h->d_arrive) return fail(F110_E_INVALID, "scan launch: the closing form needs num_agents == 1");
         a.arrive = h->d_arrive;
-        return launch_scan_t<2>(h, a, st, ev0, ev1);
+        return launch_scan_t<2>(kind, a, st, ev0, ev1);
     }
-    return a.state ? launch_scan_t<1>(h, a, st, ev0, ev1) : launch_scan_t<0>(h, a, st, ev0, ev1);
+    return a.state ? launch_scan_t<1>(kind, a, st, ev0, ev1) : launch_scan_t<0>(kind, a, st, ev0, ev1);
 }
 
 // ---- car-group path (car_group_kernel): one workgroup of `waves` wavefronts per car.  Taken only on request
@@ -1096,7 +1101,23 @@ static int run_step(f110_handle *h, const double *actions, int reset_only, const
         memset(&s, 0, sizeof(s));
         fill_scan_args(h, s, reset_only);
         if (closing) fill_fuse_args(h, s.f, actions);
-        rc = launch_scan(h, s, st, ev0, ev1);
+        if (h->multi && !(h->ident && h->pow2)) {
+            // env blocks on maps of different kinds: one launch per run of envs of one kind, so that a single map with an
+            // odd resolution or a rotated origin does not put every car on the general instantiation
+            int e0 = 0;
+            rc = F110_OK;
+            while (e0 < c.num_envs && !rc) {
+                const f110_handle::MapSlot &s0 = h->slots[h->h_env_map[e0]];
+                int e1 = e0 + 1;
+                while (e1 < c.num_envs && h->slots[h->h_env_map[e1]].ident == s0.ident && h->slots[h->h_env_map[e1]].pow2 == s0.pow2) e1++;
+                ScanArgs sub = s;
+                sub.car_base = e0 * c.num_agents;
+                sub.n_cars = (e1 - e0) * c.num_agents;
+                const MapKind kind{s0.ident, s0.pow2};
+                rc = launch_scan(h, sub, st, e0 == 0 ? ev0 : nullptr, e0 == 0 ? ev1 : nullptr, &kind);
+                e0 = e1;
+            }
+        } else rc = launch_scan(h, s, st, ev0, ev1);
     }
     if (rc) return rc;
     if (prof) h->prof_n++;

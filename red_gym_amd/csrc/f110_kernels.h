@@ -238,7 +238,9 @@ struct ScanArgs {
     const int32_t *env_map;     // dev [B] map of every env, or NULL (all envs on maps[0]); the cars of one
                                 // workgroup share a map (f110_assign_maps checks it): its LUT is staged per group
     ScanDev scan;
-    int n_cars;
+    int n_cars;             // cars of THIS launch: car_base .. car_base + n_cars - 1
+    int car_base;           // first car (a shard whose env blocks sit on maps of different kinds -- resolution a power
+                            // of two or not, origin rotated or not -- is scanned block by block, each with its own instantiation)
     int agents;             // A (cars of one env are consecutive)
     int wpc;                // wavefronts per car (power of two): small batches split a car's beams over
                             // several waves so that the chip is still filled; chunk position p goes to wave p % wpc
@@ -330,7 +332,7 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
         wpc = 1 << lg; car = st < ns ? c + (t >> lg) : a.n_cars; part = t & (wpc - 1);
     }
     // the car's map (wave-uniform: scalar loads); waves past the last car still help to stage the LUT
-    const int car_c = min(car, a.n_cars - 1);
+    const int car_c = rare->car_base + min(car, a.n_cars - 1);
     const MapDev &md = a.maps[a.env_map ? a.env_map[car_c / a.agents] : 0];
     {   // LDS image of the LUT prepared by the host (slot SLOT_BORDER = dt[-1,-1]): 16-B copies
         const double2 *src = reinterpret_cast<const double2 *>(md.lut_lds);
@@ -346,6 +348,7 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
     mv.cells_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(md.cells), 0, (int)md.cells_bytes, 0x00020000);
     mv.init(md);
     if (car >= a.n_cars) return;
+    car += rare->car_base; // (from here on the car's index in the shard)
     // this wave's slice of the car's beam queue: chunk positions part, part+wpc, ...
     const int nch = (nb + 63) >> 6;
     const int my_chunks = nch > part ? (nch - part + wpc - 1) / wpc : 0;
@@ -618,7 +621,7 @@ __global__ __launch_bounds__(GROUP_MAX_WAVES * WAVE, F110_GROUP_MIN_WAVES) void 
     const int nb = a.s.scan.nb;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int nthreads = blockDim.x, nwaves = nthreads >> 6;
-    const int car = blockIdx.x, env = car / a.s.agents;
+    const int car = a.s.car_base + blockIdx.x, env = car / a.s.agents;
     bool pend = false; // (workgroup-uniform)
     if (STEP) {
         pend = a.s.pending_reset[env] != 0;

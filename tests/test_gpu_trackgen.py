@@ -77,16 +77,21 @@ def test_generated_track_is_a_drivable_loop():
 
 
 def test_map_slots_give_env_blocks_their_own_map():
-    """Blocks of envs on different maps inside one handle scan exactly like separate single-map envs on those maps."""
+    """Blocks of envs on different maps inside one handle scan exactly like separate single-map envs on those maps --
+    maps of all four KINDS (resolution a power of two or not, origin rotated or not): the shard is then scanned block by
+    block, each block with the instantiation its own maps allow."""
     from red_gym_amd import F110VecEnv, workload, maps
     B = 96
     multi = F110VecEnv(B, map=workload.EXAMPLE_MAP, num_agents=1)
-    names = [None, 'berlin', 'skirk']
+    names = [None, 'berlin', 'skirk', 'rot']
+    specs = []
     for k, name in enumerate(names):
-        y = workload.EXAMPLE_MAP + '.yaml' if name is None else maps.builtin_map_yaml(name)
+        y = workload.EXAMPLE_MAP + '.yaml' if name in (None, 'rot') else maps.builtin_map_yaml(name)
         m = maps.load_map(y, '.png')
-        multi.eng.set_map_occupancy(m.free, m.resolution, m.orig_x, m.orig_y, float(np.arctan2(m.orig_s, m.orig_c)), slot=k)
-    assign = (np.arange(B) * 3) // B
+        theta = 0.3 if name == 'rot' else float(np.arctan2(m.orig_s, m.orig_c))
+        specs.append((m.free, m.resolution, m.orig_x, m.orig_y, theta))
+        multi.eng.set_map_occupancy(*specs[-1], slot=k)
+    assign = (np.arange(B) * 4) // B
     multi.eng.assign_maps(assign)
     rng = np.random.default_rng(0)
     poses = np.zeros((B, 1, 3))
@@ -94,10 +99,12 @@ def test_map_slots_give_env_blocks_their_own_map():
     poses[:, 0, 2] = rng.uniform(-3, 3, B)
     acts = workload.action_pool(4, B, 1)
     om = multi.reset(poses)[0]
-    singles = [F110VecEnv(B, map=(workload.EXAMPLE_MAP if n is None else n), num_agents=1) for n in names]
+    singles = [F110VecEnv(B, map=workload.EXAMPLE_MAP, num_agents=1) for n in names]
+    for sgl, spec in zip(singles, specs):
+        sgl.eng.set_map_occupancy(*spec)
     outs = [s.reset(poses)[0] for s in singles]
     for step in range(4):
-        for k in range(3):
+        for k in range(4):
             sel = torch.as_tensor(assign == k, device=multi.device)
             assert torch.equal(om['scans'][sel], outs[k]['scans'][sel]), (step, k)
             assert torch.equal(om['collisions'][sel], outs[k]['collisions'][sel])
