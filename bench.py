@@ -319,14 +319,21 @@ def main(argv=None):
             to_img(obs['scans'][:, 0], out=imgs)
         step_fn(0)
         lookups.zero_()
+    NEVER = 1 << 30  # a sampling period no run reaches: the measurement aid active, no step instrumented
     if not args.no_scan_events:
-        env.eng.profile_begin(K, every=max(1, args.scan_events_every))  # hipEvent pairs on every Nth timed scan launch
+        env.eng.profile_begin(K, every=max(1, args.scan_events_every))  # hipEvent pairs + lookup counting on every Nth timed scan launch
+    else:
+        env.eng.profile_begin(1, every=NEVER)
     elapsed = timed_steps(ranks, step_fn, K)
-    scan_prof = env.eng.profile_end() if not args.no_scan_events else None  # the K timed launches only
+    scan_prof = env.eng.profile_end()                                         # the sampled launches of the K timed steps only
+    if args.no_scan_events:
+        scan_prof = None
     tot_lookups = int(lookups.to(torch.int64).sum().item())                  # ... and their table reads
     sustained = None
     if args.sustained > 0:
+        env.eng.profile_begin(1, every=NEVER)                                # uninstrumented, like the un-sampled timed steps
         el2 = timed_steps(ranks, lambda k: step_fn(K + k), args.sustained)
+        env.eng.profile_end()
         sustained = {'value': world * B * args.sustained / el2, 'unit': 'env-steps/s', 'steps': args.sustained,
                      'ms_per_step': el2 / args.sustained * 1e3,
                      'note': 'the %d steps right after the timed region (GPU clocks up, cars scattered by random '
@@ -340,7 +347,9 @@ def main(argv=None):
             scan_ms, n_launch = scan_prof
             cars = B * A
             # SURVEY 8(d) byte model, per car-step: L*4 + 1080*4 + 72
-            bytes_per_launch = (tot_lookups / K) * 4.0 + cars * (1080 * 4 + 72)  # lookups: mean over ALL K timed launches
+            # lookups are counted by the launches that carry the events (f110_profile_every), so bytes and time are
+            # those of the same n_launch dispatches
+            bytes_per_launch = (tot_lookups / max(n_launch, 1)) * 4.0 + cars * (1080 * 4 + 72)
             avg_s = scan_ms * 1e-3 / max(n_launch, 1)
             achieved = bytes_per_launch / avg_s / 1e9
             # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE in separate
@@ -359,7 +368,7 @@ def main(argv=None):
             roof = {'bound': 'hbm', 'kernel': 'scan_kernel', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                     'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                     'avg_launch_ms': avg_s * 1e3, 'launches': n_launch,
-                    'lookups_per_car_step': tot_lookups / K / cars, 'events_every': max(1, args.scan_events_every),
+                    'lookups_per_car_step': tot_lookups / max(n_launch, 1) / cars, 'events_every': max(1, args.scan_events_every),
                     'algorithmic_bytes_per_launch': bytes_per_launch,
                     'model': 'SURVEY 8(d) algorithmic bytes: lookups*4 + cars*(1080*4 + 72), not HBM traffic',
                     'measured_hbm_gbs': (traffic / avg_s / 1e9) if traffic else None,

@@ -236,6 +236,8 @@ int f110_profile_begin(f110_handle *h, int32_t max_launches);
 /* Sampling: events ride on every `every`-th step only (default 1 = all).  A dispatch that carries events costs the
  * stream about 10 us of idle time around it (measured, profiles/r03_event_cost.txt), which a 4 096-env step notices. */
 int f110_profile_every(f110_handle *h, int32_t every);
+/* While the aid is active (between begin and end) f110_buffers.lookups is only fed by the steps that carry an event
+ * pair: the counters then hold the table reads of exactly the measured launches. */
 int f110_profile_end(f110_handle *h, double *scan_ms_total, int32_t *launches);
 
 /* Batched pure-pursuit planner, the caller on the other side of F110Env.step

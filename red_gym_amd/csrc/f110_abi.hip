@@ -1031,6 +1031,14 @@ static void fill_scan_args(const f110_handle *h, ScanArgs &s, int reset_only)
     s.out_f32 = b.scans; s.out_f64 = b.scans_f64; s.lookups = b.lookups;
 }
 
+// Instrumentation follows the measurement aid's sampling: while f110_profile_begin is active, the per-car lookup counters
+// are only fed by the steps that also carry the event pair (an atomic per wave costs 2.5 % of a 65 536-env step,
+// profiles/r03_event_cost.txt), so bytes and time of the roofline come from the same launches.
+static void sample_lookups(const f110_handle *h, bool sampled_step, ScanArgs &s)
+{
+    if (h->prof_on && !sampled_step) s.lookups = nullptr;
+}
+
 static void fill_fuse_args(const f110_handle *h, FuseArgs &f, const double *actions)
 {
     const f110_config &c = h->cfg;
@@ -1093,6 +1101,7 @@ static int run_step(f110_handle *h, const double *actions, int reset_only, const
         GroupArgs g;
         memset(&g, 0, sizeof(g));
         fill_scan_args(h, g.s, reset_only);
+        sample_lookups(h, prof, g.s);
         g.order = h->d_order;
         if (closing) fill_fuse_args(h, g.s.f, actions);
         rc = launch_group(h, g, closing ? 3 : 1, gw, st, ev0, ev1);
@@ -1100,6 +1109,7 @@ static int run_step(f110_handle *h, const double *actions, int reset_only, const
         ScanArgs s;
         memset(&s, 0, sizeof(s));
         fill_scan_args(h, s, reset_only);
+        sample_lookups(h, prof, s);
         if (closing) fill_fuse_args(h, s.f, actions);
         if (h->multi && !(h->ident && h->pow2)) {
             // env blocks on maps of different kinds: one launch per run of envs of one kind, so that a single map with an
