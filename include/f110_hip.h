@@ -189,24 +189,6 @@ int f110_step(f110_handle *h, const double *actions_dev, void *stream);
  * has) is refused with F110_E_INVALID and changes nothing.  Results do not depend on it. */
 int f110_set_scan_stages(f110_handle *h, const char *spec);
 
-/* Which kernels a step enqueues.
- * F110_PATH_CLASSIC: dynamics_kernel -> scan_kernel (a wavefront per car, or a fixed slice of its beams per wavefront)
- *   -> [opponent kernels] -> env_kernel.
- * F110_PATH_CLOSED (num_agents == 1 only): dynamics_kernel -> scan_kernel in its closing form: the last wavefront of a
- *   car to finish its rays also does the bookkeeping of F110Env.step / _check_done for that car (f110_env.py:261-302,
- *   base_classes.py:241-250), so a step is two launches instead of three.
- * F110_PATH_GROUP: one WORKGROUP of `waves_per_car` wavefronts (1..8; 0 = built-in choice) per car, whose waves draw
- *   beams from one queue (closing for one agent); an alternative launch shape kept for experiments.
- * F110_PATH_AUTO (default): classic -- on MI355X neither alternative beats it (profiles/r03_step_forms.txt): the
- *   lane-per-env env_kernel (5 us) is cheaper than one lane per car at the end of every scan wave, and a small
- *   launch lasts as long as its longest ray's dependent chain whatever the launch shape.
- * Results do not depend on the path (same device functions; a beam's value does not depend on the lane that marched it). */
-#define F110_PATH_AUTO 0
-#define F110_PATH_CLASSIC 1
-#define F110_PATH_GROUP 2
-#define F110_PATH_CLOSED 3
-int f110_set_step_path(f110_handle *h, int32_t path, int32_t waves_per_car);
-
 /* hipGraph support.  f110_step only enqueues kernels (no allocation, no synchronisation), so it can be captured
  * into a HIP graph and replayed.  A capture freezes the kernel selection and the by-value launch arguments; the
  * calls that change them -- f110_bind, f110_set_tables, f110_set_noise_table (the table is re-allocated), every map

@@ -66,7 +66,6 @@ SYMBOLS = {
     'f110_reset': [_VP, _VP, _VP, _VP],
     'f110_step': [_VP, _VP, _VP],
     'f110_set_scan_stages': [_VP, C.c_char_p],
-    'f110_set_step_path': [_VP, _I32, _I32],
     'f110_launch_epoch': [_VP, C.POINTER(C.c_int64)],
     'f110_graph_create': [_VP, _VP, _I32, C.POINTER(_VP)],
     'f110_graph_launch': [_VP, _VP],

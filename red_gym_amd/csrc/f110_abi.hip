@@ -47,15 +47,11 @@ struct f110_handle {
     Params agent_params[F110_MAX_AGENTS]; // RaceCar.params per agent index
     Params *d_agent_params = nullptr;
     OppPair *d_opp_pairs = nullptr;   // [N, A-1] opponent ray-cast scratch
-    uint32_t *d_arrive = nullptr;     // [N] arrival counters of the closing scan_kernel (zero between launches)
-    uint16_t *d_order = nullptr;      // [N, ORDER_STRIDE] per-car chunk order of the car-group path (a hint, see GroupArgs)
     bool has_map = false, bound = false;
     // Bumped whenever a later f110_step would enqueue different kernels or by-value arguments than an earlier one
     // (a table re-allocated, another scan instantiation selected, buffers re-bound): f110_launch_epoch.
     int64_t epoch = 0;
     std::string stages;               // f110_set_scan_stages override ("" = F110_STAGES or the built-in choice)
-    int step_path = F110_PATH_AUTO;   // f110_set_step_path
-    int group_waves = 0;              // wavefronts per car of the car-group path (0 = built-in choice)
     f110_buffers bufs;
     // device tables owned by the handle
     double *d_scan_angles = nullptr, *d_beam_cosines = nullptr, *d_side = nullptr;
@@ -236,18 +232,6 @@ static int upload_beam_cs(f110_handle *h, const double *scan_angles)
 static int upload_agent_params(f110_handle *h);
 static int rebuild_noise_side(f110_handle *h);
 
-// per-car chunk order of the car-group path: starts invalid (= the static order)
-static int alloc_order(f110_handle *h)
-{
-    const size_t n = (size_t)h->cfg.num_envs * h->cfg.num_agents * ORDER_STRIDE;
-    HIP_TRY(hipMalloc((void **)&h->d_order, n * sizeof(uint16_t)));
-    HIP_TRY(hipMemset(h->d_order, 0, n * sizeof(uint16_t)));
-    const size_t cars = (size_t)h->cfg.num_envs * h->cfg.num_agents;
-    HIP_TRY(hipMalloc((void **)&h->d_arrive, cars * sizeof(uint32_t)));
-    HIP_TRY(hipMemset(h->d_arrive, 0, cars * sizeof(uint32_t)));
-    return F110_OK;
-}
-
 // scratch of the opponent ray cast: allocated here, never in f110_step
 static int alloc_opp_pairs(f110_handle *h)
 {
@@ -310,7 +294,7 @@ extern "C" int f110_create(const f110_config *cfg, f110_handle **out)
     if ((rc = upload_cs(h)) || (rc = rebuild_noise_side(h)) ||
         (rc = upload(&h->d_scan_angles, ang.data(), ang.size())) || (rc = upload_beam_cs(h, ang.data())) ||
         (rc = upload(&h->d_beam_cosines, bcos.data(), bcos.size())) ||
-        (rc = upload(&h->d_side, side.data(), side.size())) || (rc = set_beam_order(h)) || (rc = upload_agent_params(h)) || (rc = alloc_opp_pairs(h)) || (rc = alloc_order(h))) {
+        (rc = upload(&h->d_side, side.data(), side.size())) || (rc = set_beam_order(h)) || (rc = upload_agent_params(h)) || (rc = alloc_opp_pairs(h))) {
         f110_destroy(h);
         return rc;
     }
@@ -323,7 +307,7 @@ extern "C" void f110_destroy(f110_handle *h)
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
     void *ptrs[] = {h->d_cs, h->d_beam_cs, h->d_noise_side, h->d_scan_angles, h->d_beam_cosines, h->d_side,
-                    h->d_chunk0, h->d_agent_params, h->d_opp_pairs, h->d_maps, h->d_env_map, h->d_order, h->d_arrive};
+                    h->d_chunk0, h->d_agent_params, h->d_opp_pairs, h->d_maps, h->d_env_map};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &sl : h->slots)
@@ -892,9 +876,6 @@ static int check_scan_args(const ScanArgs &a, const char *who)
     if (a.state && (!a.noise_step || !a.noise_side || a.noise_T < 1 || !a.beam_cosines || !a.in_collision || !a.pending_reset))
         return fail(F110_E_INVALID, "%s: a buffer of the step's scan is missing (noise / beam cosines / in_collision / pending_reset)", who);
     if (!a.state && a.reset_only) return fail(F110_E_INVALID, "%s: reset_only without the step's buffers", who);
-    if (a.f.state && (!a.f.noise_step || !a.f.spawn || !a.f.pending_reset || !a.f.in_collision || !a.f.collisions || !a.f.collision_idx ||
-                      !a.f.start_rot || !a.f.near_start || !a.f.toggles || !a.f.lap_counts || !a.f.lap_times || !a.f.current_time || !a.f.done))
-        return fail(F110_E_INVALID, "%s: a buffer of the closing form is missing", who);
     return F110_OK;
 }
 
@@ -963,59 +944,7 @@ static int launch_scan(f110_handle *h, const ScanArgs &a_in, const Sink &st, hip
 #if defined(F110_TIMELINE)
     a.timeline = timeline_buffer();
 #endif
-    if (a.f.state) { // the closing form (one agent): the arrival counters of split cars
-        if (a.agents != 1 || !h->d_arrive) return fail(F110_E_INVALID, "scan launch: the closing form needs num_agents == 1");
-        a.arrive = h->d_arrive;
-        return launch_scan_t<2>(kind, a, st, ev0, ev1);
-    }
     return a.state ? launch_scan_t<1>(kind, a, st, ev0, ev1) : launch_scan_t<0>(kind, a, st, ev0, ev1);
-}
-
-// ---- car-group path (car_group_kernel): one workgroup of `waves` wavefronts per car.  Taken only on request
-// (f110_set_step_path(F110_PATH_GROUP), or F110_GROUP="waves[:max_cars]" for sweeps): measured on MI355X
-// (profiles/r03_group_*.txt) it matches the classic stage lists but does not beat them.  Returns the wavefronts per car.
-static int group_waves_for(const f110_handle *h, int n_cars)
-{
-    static const char *env = getenv("F110_GROUP");
-    int waves = 0, max_cars = 0x7fffffff;
-    if (env) {
-        char *e = nullptr;
-        waves = (int)strtol(env, &e, 10);
-        if (e && *e == ':') max_cars = (int)strtol(e + 1, nullptr, 10);
-        if (waves == 0 && h->step_path != F110_PATH_GROUP) return 0; // F110_GROUP=0
-    }
-    if (h->group_waves) waves = h->group_waves;
-    if (h->step_path != F110_PATH_GROUP && n_cars > max_cars) return 0;
-    if (waves == 0) waves = n_cars <= 1024 ? 8 : 4;
-    return std::max(1, std::min(GROUP_MAX_WAVES, waves));
-}
-
-template <int MODE>
-static int launch_group_t(f110_handle *h, const GroupArgs &a, int waves, const Sink &k, hipEvent_t ev0, hipEvent_t ev1)
-{
-    const dim3 grid(a.s.n_cars), block(waves * WAVE);
-    const void *f = h->ident && h->pow2 ? (const void *)&car_group_kernel<true, true, MODE>
-                  : h->ident            ? (const void *)&car_group_kernel<true, false, MODE>
-                  : h->pow2             ? (const void *)&car_group_kernel<false, true, MODE>
-                                        : (const void *)&car_group_kernel<false, false, MODE>;
-    return emit(k, f, grid, block, 0, a, ev0, ev1);
-}
-
-static int launch_group(f110_handle *h, const GroupArgs &a, int mode, int waves, const Sink &st, hipEvent_t ev0 = nullptr,
-                        hipEvent_t ev1 = nullptr)
-{
-    if (a.s.n_cars < 1 || waves < 1 || waves > GROUP_MAX_WAVES) return fail(F110_E_INVALID, "car-group launch: %d cars, %d waves per car", a.s.n_cars, waves);
-    if (int rc_args = check_scan_args(a.s, "car-group launch")) return rc_args;
-    if (mode != 0 && mode != 1 && mode != 3) return fail(F110_E_INVALID, "car-group launch: mode %d", mode);
-    if (mode == 3 && a.s.agents != 1) return fail(F110_E_INVALID, "the closing car groups need num_agents == 1");
-#if defined(F110_TIMELINE)
-    GroupArgs at = a;
-    at.s.timeline = timeline_buffer();
-    return mode == 3 ? launch_group_t<3>(h, at, waves, st, ev0, ev1)
-         : mode == 1 ? launch_group_t<1>(h, at, waves, st, ev0, ev1) : launch_group_t<0>(h, at, waves, st, ev0, ev1);
-#endif
-    return mode == 3 ? launch_group_t<3>(h, a, waves, st, ev0, ev1)
-         : mode == 1 ? launch_group_t<1>(h, a, waves, st, ev0, ev1) : launch_group_t<0>(h, a, waves, st, ev0, ev1);
 }
 
 static void fill_scan_args(const f110_handle *h, ScanArgs &s, int reset_only)
@@ -1039,52 +968,17 @@ static void sample_lookups(const f110_handle *h, bool sampled_step, ScanArgs &s)
     if (h->prof_on && !sampled_step) s.lookups = nullptr;
 }
 
-static void fill_fuse_args(const f110_handle *h, FuseArgs &f, const double *actions)
-{
-    const f110_config &c = h->cfg;
-    const f110_buffers &b = h->bufs;
-    f.state = b.state; f.steer_buf = b.steer_buf; f.steer_cnt = b.steer_cnt; f.noise_step = b.noise_step; f.actions = actions;
-    f.spawn = b.spawn; f.pending_reset = b.pending_reset; f.pose_snap = b.pose_snap; f.in_collision = b.in_collision;
-    f.agent_params = h->d_agent_params; f.time_step = c.timestep; f.integrator = c.integrator; f.autoreset = c.autoreset;
-    f.collisions = b.collisions; f.collision_idx = b.collision_idx; f.start_rot = b.start_rot; f.near_start = b.near_start;
-    f.toggles = b.toggles; f.lap_counts = b.lap_counts; f.lap_times = b.lap_times; f.current_time = b.current_time;
-    f.done = b.done; f.checkpoint_done = b.checkpoint_done;
-}
-
-// The step of every env.  Forms (f110_set_step_path; AUTO picks by size, see step_form):
-//   classic  dynamics_kernel -> scan_kernel -> [opp_setup_kernel, opp_apply_kernel] -> env_kernel
-//   closed   dynamics_kernel -> scan_kernel<SM 2>, which also does env_kernel's work (one agent only)
-//   group    dynamics_kernel -> car_group_kernel (a workgroup per car; closing for one agent) [-> opponents -> env_kernel]
-enum StepForm { FORM_CLASSIC, FORM_CLOSED, FORM_GROUP };
-
-static StepForm step_form(const f110_handle *h, int n_cars, int *group_waves)
-{
-    *group_waves = 0;
-    if (h->step_path == F110_PATH_GROUP || (h->step_path == F110_PATH_AUTO && getenv("F110_GROUP"))) {
-        *group_waves = group_waves_for(h, n_cars);
-        if (*group_waves) return FORM_GROUP;
-    }
-    if (h->cfg.num_agents != 1 || h->step_path == F110_PATH_CLASSIC) return FORM_CLASSIC;
-    if (h->step_path == F110_PATH_CLOSED) return FORM_CLOSED;
-    // AUTO is classic at every size: measured on MI355X (profiles/r03_step_forms.txt) the closing scan is 2..9 %
-    // SLOWER than scan_kernel + env_kernel (a lane-per-env kernel of 5 us does the bookkeeping of 64 cars per wave
-    // instruction; one lane per car at the end of every wave does not), and the car groups only match the classic
-    // stage lists.  F110_CLOSED_MAX=<cars> makes AUTO take the closing scan up to that size (sweeps).
-    static const int closed_max = getenv("F110_CLOSED_MAX") ? atoi(getenv("F110_CLOSED_MAX")) : 0;
-    return n_cars <= closed_max ? FORM_CLOSED : FORM_CLASSIC;
-}
-
+// The step of every env: dynamics_kernel -> scan_kernel -> [opp_setup_kernel, opp_apply_kernel] -> env_kernel.  (Two other
+// forms -- a scan that also closes the step of a one-agent env, and a workgroup per car with a shared beam queue -- were
+// built, held to ==, measured slower at every size and removed: tools/variants/car_group_and_closing_scan.patch,
+// profiles/r03_step_forms.txt.)
 static int run_step(f110_handle *h, const double *actions, int reset_only, const Sink &st)
 {
     const f110_config &c = h->cfg;
     const f110_buffers &b = h->bufs;
     const int N = c.num_envs * c.num_agents;
-    int gw = 0;
-    const StepForm form = step_form(h, N, &gw);
     const bool prof = h->prof_on && !st.record && (h->prof_seq++ % h->prof_every) == h->prof_every / 2 && (size_t)(2 * h->prof_n + 1) < h->prof_ev.size();
     hipEvent_t ev0 = prof ? h->prof_ev[2 * h->prof_n] : nullptr, ev1 = prof ? h->prof_ev[2 * h->prof_n + 1] : nullptr;
-    static const bool nofuse = getenv("F110_GROUP_NOFUSE") != nullptr;     // sweeps: car groups for the scan only
-    const bool closing = c.num_agents == 1 && (form == FORM_CLOSED || (form == FORM_GROUP && !nofuse));
     int rc;
 
     {
@@ -1097,20 +991,11 @@ static int run_step(f110_handle *h, const double *actions, int reset_only, const
     }
 
     // the scan (the launch the measurement aid brackets)
-    if (form == FORM_GROUP) {
-        GroupArgs g;
-        memset(&g, 0, sizeof(g));
-        fill_scan_args(h, g.s, reset_only);
-        sample_lookups(h, prof, g.s);
-        g.order = h->d_order;
-        if (closing) fill_fuse_args(h, g.s.f, actions);
-        rc = launch_group(h, g, closing ? 3 : 1, gw, st, ev0, ev1);
-    } else {
+    {
         ScanArgs s;
         memset(&s, 0, sizeof(s));
         fill_scan_args(h, s, reset_only);
         sample_lookups(h, prof, s);
-        if (closing) fill_fuse_args(h, s.f, actions);
         if (h->multi && !(h->ident && h->pow2)) {
             // env blocks on maps of different kinds: one launch per run of envs of one kind, so that a single map with an
             // odd resolution or a rotated origin does not put every car on the general instantiation
@@ -1131,7 +1016,6 @@ static int run_step(f110_handle *h, const double *actions, int reset_only, const
     }
     if (rc) return rc;
     if (prof) h->prof_n++;
-    if (closing) return F110_OK;
 
     if (c.num_agents > 1) {
         OppArgs o;
@@ -1307,21 +1191,6 @@ extern "C" int f110_set_scan_stages(f110_handle *h, const char *spec)
             return fail(F110_E_INVALID, "f110_set_scan_stages: \"%s\" names %lld cars, the handle has %d", spec, fixed, h->cfg.num_envs * h->cfg.num_agents);
     }
     h->stages = spec ? spec : "";
-    h->epoch++;
-    return F110_OK;
-}
-
-extern "C" int f110_set_step_path(f110_handle *h, int32_t path, int32_t waves_per_car)
-{
-    if (!h) return fail(F110_E_INVALID, "f110_set_step_path: null handle");
-    if (path != F110_PATH_AUTO && path != F110_PATH_CLASSIC && path != F110_PATH_GROUP && path != F110_PATH_CLOSED)
-        return fail(F110_E_INVALID, "f110_set_step_path: path %d (0 auto, 1 classic, 2 car groups, 3 closing scan)", path);
-    if (path == F110_PATH_CLOSED && h->cfg.num_agents != 1)
-        return fail(F110_E_INVALID, "f110_set_step_path: the closing scan needs num_agents == 1 (the handle has %d)", h->cfg.num_agents);
-    if (waves_per_car < 0 || waves_per_car > GROUP_MAX_WAVES)
-        return fail(F110_E_INVALID, "f110_set_step_path: %d wavefronts per car (0 = built-in choice, 1..%d)", waves_per_car, GROUP_MAX_WAVES);
-    h->step_path = path;
-    h->group_waves = waves_per_car;
     h->epoch++;
     return F110_OK;
 }
@@ -1504,15 +1373,6 @@ extern "C" int f110_scan(f110_handle *h, const double *poses, int32_t n, double 
     s.maps = h->d_maps; s.scan = scan_dev(h); s.n_cars = n; s.agents = 1;
     s.pose_src = poses; s.pose_stride = 3; s.yaw_off = 2;
     s.out_f32 = out32; s.out_f64 = out64; s.lookups = lookups; s.noise_T = 1; s.chunk_beam0 = h->d_chunk0;
-    int gw = 0;
-    if (step_form(h, n, &gw) == FORM_GROUP) {
-        GroupArgs g;
-        memset(&g, 0, sizeof(g));
-        g.s = s;
-        Sink k;
-        k.st = (hipStream_t)stream;
-        return launch_group(h, g, 0, gw, k);
-    }
     Sink k;
     k.st = (hipStream_t)stream;
     return launch_scan(h, s, k);

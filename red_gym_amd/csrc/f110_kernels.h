@@ -25,7 +25,7 @@ __device__ inline int med3_i32(int x, int lo, int hi)
 __device__ inline unsigned long long vote(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
 constexpr int WAVE = 64;
-constexpr int GROUP_MAX_WAVES_TL = 8; // (diagnostics builds: per-wave stamps of a workgroup)
+constexpr int TL_MAX_WAVES = 8; // (diagnostics builds: per-wave stamps of a workgroup)
 #ifndef F110_SCAN_WAVES
 #define F110_SCAN_WAVES 2
 #endif
@@ -206,33 +206,6 @@ __device__ inline int beam_theta_index(unsigned long long T0, double t0w, int b,
     return idx;
 }
 
-// What dynamics_kernel and env_kernel take: used by the scan kernels that also close the step of a one-agent env
-// (scan_kernel SM 2, car_group_kernel MODE 2 / 3).
-struct FuseArgs {
-    double *state;              // [N,7]
-    double *steer_buf;          // [N,2]
-    int32_t *steer_cnt;         // [N]
-    int32_t *noise_step;        // [N]
-    const double *actions;      // [N,2] or NULL (reset)
-    const double *spawn;        // [N,3]
-    uint8_t *pending_reset;     // [B]
-    double *pose_snap;          // [N,3]
-    uint8_t *in_collision;      // [N]
-    const Params *agent_params;
-    double time_step;
-    int integrator, autoreset;
-    uint8_t *collisions;        // [N]
-    int32_t *collision_idx;     // [N]
-    double *start_rot;          // [B,4]
-    uint8_t *near_start;        // [N]
-    int32_t *toggles;           // [N]
-    int32_t *lap_counts;        // [N]
-    double *lap_times;          // [N]
-    double *current_time;       // [B]
-    uint8_t *done;              // [B]
-    uint8_t *checkpoint_done;   // [N] or NULL
-};
-
 struct ScanArgs {
     const MapDev *maps;         // dev [K] map descriptors
     const int32_t *env_map;     // dev [B] map of every env, or NULL (all envs on maps[0]); the cars of one
@@ -267,8 +240,6 @@ struct ScanArgs {
     float *out_f32;              // [N,nb] or NULL
     double *out_f64;             // [N,nb] or NULL
     uint32_t *lookups;           // [N] or NULL (accumulated)
-    FuseArgs f;                  // closing kernels only (else zero)
-    uint32_t *arrive;            // [N] closing scan_kernel: waves of a split car that have finished (+ 0x10000 per wave with an iTTC hit); zero between launches
     unsigned long long *timeline; // diagnostics (builds with -DF110_TIMELINE only, tools/timeline.py): per wave
                                   // {start, rays started, end} in 100 MHz ticks and (car << 8 | part); else NULL
 };
@@ -290,18 +261,14 @@ static_assert(sizeof(((ScanArgs *)0)->stage_cars) == SCAN_MAX_STAGES * sizeof(in
               sizeof(((ScanArgs *)0)->stage_log2w) == SCAN_MAX_STAGES * sizeof(int), "stage list capacity");
 static_assert(sizeof(ScanArgs) <= 4096, "kernarg segment size");
 
-__device__ inline void close_car_step(const FuseArgs *F, int car, bool pend, bool anyhit, int row, double st[7], bool write_state); // (below)
-
-// SM 0: ScanSimulator2D.scan(pose, None); 1: the scan of a step (noise, iTTC flag; env_kernel follows); 2: the scan of
-// a ONE-AGENT step that also closes it: the last wave of a car to finish (a per-car arrival counter when the car is
-// split over several waves) does env_kernel's work for that car, so the step is dynamics_kernel + this launch.
+// SM 0: ScanSimulator2D.scan(pose, None); 1: the scan of a step (noise, iTTC flag; env_kernel follows).
 template <bool IDENT, bool POW2, int SM>
 #ifndef F110_SCAN_MIN_WAVES
 #define F110_SCAN_MIN_WAVES 8
 #endif
 __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel(ScanArgs a)
 {
-    constexpr bool STEP = SM >= 1, CLOSE = SM == 2;
+    constexpr bool STEP = SM >= 1;
     __shared__ __attribute__((aligned(16))) double s_lut[LUT_LDS];
     __shared__ int s_chunk0[MAX_CHUNKS];
     // the same argument block addressed through the kernarg segment (ScanArgs is the only kernel argument): rarely
@@ -312,7 +279,7 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
     const ScanArgs *rare = &a; // host pass of the single-source compile: never executed
 #endif
 #if defined(F110_TIMELINE)
-    __shared__ volatile unsigned long long s_tl[GROUP_MAX_WAVES_TL][2]; // stamps wait in LDS, not in registers, for the end of the wave
+    __shared__ volatile unsigned long long s_tl[TL_MAX_WAVES][2]; // stamps wait in LDS, not in registers, for the end of the wave
 #endif
     const int nb = a.scan.nb;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -487,351 +454,9 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
 
     // ---- iTTC result: the flag only; env_kernel zeroes the state (base_classes.py:241-250)
     // once every wave of the car is done.  Plain store: all writers store the same 1.
-    if (STEP && !CLOSE) {
+    if (STEP) {
         if (vote(hit) != 0ull && lane == 0) ra->in_collision[car] = 1;
     }
-    if (CLOSE) {
-        // A == 1 (env == car).  The last of the car's waves to get here closes its step.  The counter also carries the
-        // waves' iTTC hits, so nothing but the atomic itself has to be visible across CUs; it is zero again afterwards.
-        const bool whit = vote(hit) != 0ull;
-        bool last = true, anyhit = whit;
-        if (wpc > 1) {
-            unsigned old = 0;
-            if (lane == 0) old = atomicAdd(&ra->arrive[car], 1u | (whit ? 0x10000u : 0u));
-            old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
-            last = (int)(old & 0xffffu) == wpc - 1;
-            anyhit = whit || (old >> 16) != 0u;
-        }
-        if (!last || lane != 0) return;
-        if (wpc > 1) ra->arrive[car] = 0;
-        const FuseArgs *F = &ra->f;
-        double st[7];
-#pragma unroll
-        for (int i = 0; i < 7; i++) st[i] = F->state[(size_t)car * 7 + i]; // written by dynamics_kernel, read-only in this launch until here
-        close_car_step(F, car, F->pending_reset[car] != 0, anyhit, F->noise_step[car], st, false);
-    }
-}
-
-// ------------------------------------------------------------------ car-group kernel (small launches)
-// scan_kernel gives a car ONE wavefront (or a fixed slice of the beam queue per wave): right when 8 192 waves fill the
-// chip several times over, wrong for a few thousand cars -- the chip is then underfilled, a launch lasts as long as
-// its slowest whole-car wave, and the two small kernels around the scan (dynamics, env bookkeeping) are a fifth of the
-// step.  Here ONE WORKGROUP of 2..8 wavefronts serves one car:
-//   * its waves draw beams from ONE queue (an LDS counter: `ds_add_rtn` per refill), so they finish together
-//     whatever the car's mix of long and short rays -- no static slices, no slice whose rays happen to be long;
-//   * MODE 3 (A == 1) also closes the step: the last wave of the group to finish its rays (LDS arrival counter, which
-//     also carries the iTTC hits) does the env bookkeeping of env_kernel for its car (collision flags, iTTC zeroing,
-//     noise row, lap logic, done, autoreset).  No GJK at A == 1.  (A MODE 2 that also integrated the car -- wave 0 running
-//     update_pose while the others staged the LUT, the whole step in ONE launch -- was built, held to == and dropped:
-//     update_pose wants 144 VGPRs, under this kernel's 64 it spilled 160-260 registers to scratch, and one pass per CAR
-//     replaced 64 lane-parallel ones: 0.200 against 0.117 ms at 4 096 envs; tools/variants/fused_step_mode2.patch.)
-// Results are those of dynamics_kernel -> scan_kernel -> env_kernel bit for bit: a beam's value does not depend on
-// the lane that marched it, and the device functions are shared.
-constexpr int GROUP_MAX_WAVES = 8;
-
-__device__ inline bool check_done_dev(const double *xy, int stride, const double *start, int A, double r00, double r01,
-                                      double r10, double r11, double current_time, uint8_t *near_start, int32_t *toggles,
-                                      int32_t *lap_counts, double *lap_times, uint8_t *checkpoint_done); // (below)
-
-// env_kernel's work for ONE car of a one-agent env, done by the last wave of the car to finish its rays: the iTTC
-// state update (base_classes.py:244-247), collision flags (:581-582; no other car, so Simulator.check_collision finds
-// nothing), noise row, F110Env.reset bookkeeping for a pending env (f110_env.py:318-329), time, lap logic and done
-// (:292-302), autoreset arming.  st: the car's state after integration; write_state: store it even without a hit.
-__device__ inline void close_car_step(const FuseArgs *F, int car, bool pend, bool anyhit, int row, double st[7], bool write_state)
-{
-    const int env = car;
-    if (anyhit) { st[3] = 0.; st[4] = 0.; st[5] = 0.; st[6] = 0.; } // check_ttc, base_classes.py:244-247
-    if (write_state || anyhit) {
-#pragma unroll
-        for (int i = 0; i < 7; i++) F->state[(size_t)car * 7 + i] = st[i];
-    }
-    F->noise_step[car] = row + 1;                 // one noise row consumed per scan
-    F->in_collision[car] = anyhit ? 1 : 0;
-    F->collisions[car] = anyhit ? 1 : 0;          // no other car: Simulator.check_collision finds nothing (:529-543), :581-582
-    F->collision_idx[car] = -1;
-    double ct = F->current_time[env];
-    double r00, r01, r10, r11;
-    if (pend) {
-        // F110Env.reset (f110_env.py:318-329)
-        ct = 0.0;
-        const double th = -F->spawn[(size_t)car * 3 + 2];
-        r00 = cos(th); r01 = -sin(th); r10 = sin(th); r11 = cos(th);
-        F->start_rot[(size_t)env * 4] = r00; F->start_rot[(size_t)env * 4 + 1] = r01;
-        F->start_rot[(size_t)env * 4 + 2] = r10; F->start_rot[(size_t)env * 4 + 3] = r11;
-        F->near_start[car] = 1; F->toggles[car] = 0;
-    } else {
-        r00 = F->start_rot[(size_t)env * 4]; r01 = F->start_rot[(size_t)env * 4 + 1];
-        r10 = F->start_rot[(size_t)env * 4 + 2]; r11 = F->start_rot[(size_t)env * 4 + 3];
-    }
-    ct = ct + F->time_step; // f110_env.py:293
-    F->current_time[env] = ct;
-    const bool all_done = check_done_dev(st, 7, F->spawn + (size_t)car * 3, 1, r00, r01, r10, r11, ct, F->near_start + car,
-                                         F->toggles + car, F->lap_counts + car, F->lap_times + car,
-                                         F->checkpoint_done ? F->checkpoint_done + car : nullptr);
-    const bool dn = anyhit || all_done;
-    F->done[env] = dn ? 1 : 0;
-    F->pending_reset[env] = (F->autoreset && dn) ? 1 : 0;
-}
-
-
-
-
-// Per car, from its previous scan: the order in which its 64-beam chunks are handed out, longest-lived rays first,
-// and how long its longest ray lived.  A hint only -- any permutation of the full chunks gives the same bits -- but
-// it decides when a small launch ends: a launch lasts until its slowest ray is done, the slowest rays (a few hundred
-// dependent lookups creeping along a wall) are the same beams from one step to the next, and a ray that is started at
-// once and not slowed by its SIMD neighbours ends tens of microseconds earlier than one taken late from the queue.
-constexpr int ORDER_STRIDE = MAX_CHUNKS + 2;    // u16 per car: chunk order [MAX_CHUNKS], longest ray age, valid flag
-constexpr int ORDER_AGE = MAX_CHUNKS, ORDER_VALID = MAX_CHUNKS + 1;
-#ifndef F110_GROUP_PRIO_AGE
-#define F110_GROUP_PRIO_AGE 150   // a car whose longest ray lived this many wave iterations last time runs at raised priority
-#endif
-
-struct GroupArgs {
-    ScanArgs s;                 // wpc / stage list unused: the grid is one workgroup per car
-    uint16_t *order;            // [N, ORDER_STRIDE] or NULL (static order, nothing recorded)
-};
-static_assert(__is_trivially_copyable(GroupArgs) && offsetof(GroupArgs, s) == 0 && sizeof(GroupArgs) <= 4096,
-              "car_group_kernel re-reads its only argument through the kernarg segment pointer");
-
-// MODE 0: ScanSimulator2D.scan(pose, None); 1: the scan of a step (noise, iTTC flag); 3: scan + env bookkeeping of a
-// step whose dynamics_kernel has run (A == 1)
-template <bool IDENT, bool POW2, int MODE>
-#ifndef F110_GROUP_MIN_WAVES
-#define F110_GROUP_MIN_WAVES 8
-#endif
-__global__ __launch_bounds__(GROUP_MAX_WAVES * WAVE, F110_GROUP_MIN_WAVES) void car_group_kernel(GroupArgs a)
-{
-    static_assert(MODE == 0 || MODE == 1 || MODE == 3, "car_group_kernel modes");
-    constexpr bool STEP = MODE >= 1, CLOSE = MODE == 3; // CLOSE: the last wave does env_kernel's work
-    __shared__ __attribute__((aligned(16))) double s_lut[LUT_LDS];
-    __shared__ int s_chunk0[MAX_CHUNKS];
-    __shared__ unsigned s_next;     // head of the car's beam queue
-    __shared__ unsigned s_arrive;   // waves that have finished their rays (+ 0x10000 per wave with an iTTC hit)
-    __shared__ unsigned s_cmax[MAX_CHUNKS]; // longest ray life (wave iterations) seen in each chunk of this scan
-#if defined(__HIP_DEVICE_COMPILE__)
-    const GroupArgs *rare = (const GroupArgs *)__builtin_amdgcn_kernarg_segment_ptr();
-#else
-    const GroupArgs *rare = &a; // host pass of the single-source compile: never executed
-#endif
-#if defined(F110_TIMELINE)
-    __shared__ volatile unsigned long long s_tl[GROUP_MAX_WAVES_TL][2];
-    __shared__ volatile unsigned s_tlw[GROUP_MAX_WAVES_TL];
-#endif
-    const int nb = a.s.scan.nb;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int nthreads = blockDim.x, nwaves = nthreads >> 6;
-    const int car = a.s.car_base + blockIdx.x, env = car / a.s.agents;
-    bool pend = false; // (workgroup-uniform)
-    if (STEP) {
-        pend = a.s.pending_reset[env] != 0;
-        if (a.s.reset_only && !pend) return;
-    }
-    const MapDev &md = a.s.maps[a.s.env_map ? a.s.env_map[env] : 0];
-    {
-        const double2 *src = reinterpret_cast<const double2 *>(md.lut_lds);
-        double2 *dst = reinterpret_cast<double2 *>(s_lut);
-        for (int i = threadIdx.x; i < LUT_LDS / 2; i += nthreads) dst[i] = src[i];
-    }
-    // chunk order: the car's own from its previous scan, else the static one (long rays along the car's axis first)
-    const bool rec = a.order != nullptr; // (the pointer itself is re-read from the argument block where it is needed)
-    {
-        const uint16_t *order = rec ? a.order + (size_t)car * ORDER_STRIDE : nullptr;
-        const bool own_order = rec && order[ORDER_VALID] != 0;
-        for (int i = threadIdx.x; i < ((nb + 63) >> 6); i += nthreads) s_chunk0[i] = own_order ? order[i] : a.s.chunk_beam0[i];
-        for (int i = threadIdx.x; i < MAX_CHUNKS; i += nthreads) s_cmax[i] = 0;
-        if (own_order && order[ORDER_AGE] >= F110_GROUP_PRIO_AGE) __builtin_amdgcn_s_setprio(2);
-    }
-    if (threadIdx.x == 0) { s_next = 0; s_arrive = 0; }
-#if defined(F110_TIMELINE)
-    { unsigned long long t = wall_clock64(); asm volatile("" : "+v"(t)); if (lane == 0) s_tl[wave][0] = t; }
-#endif
-    __syncthreads();
-    MapView mv;
-    mv.cells_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(md.cells), 0, (int)md.cells_bytes, 0x00020000);
-    mv.init(md);
-
-    double vel = 0.0;
-    int row = 0;
-    const double px = a.s.pose_src[(size_t)car * a.s.pose_stride];
-    const double py = a.s.pose_src[(size_t)car * a.s.pose_stride + 1];
-    const double yaw = a.s.pose_src[(size_t)car * a.s.pose_stride + a.s.yaw_off];
-    if (STEP) { vel = a.s.state[(size_t)car * 7 + 3]; row = a.s.noise_step[car]; }
-    const double eps = a.s.scan.eps, max_range = a.s.scan.max_range;
-    const bool do_ttc = STEP && vel != 0.0;               // laser_models.py:206
-    const double cand = a.s.ttc_thresh * fabs(vel) * 1.000000001; // see scan_kernel
-    const double2 *__restrict__ ns = STEP ? a.s.noise_side + (size_t)((long long)row % a.s.noise_T) * nb : nullptr;
-    float *o32 = a.s.out_f32 ? a.s.out_f32 + (size_t)car * nb : nullptr;
-    double *o64 = a.s.out_f64 ? a.s.out_f64 + (size_t)car * nb : nullptr;
-    bool hit = false;
-
-    auto emit = [&](int i, double tot, double nzv, double sdv) {
-        double v = __builtin_fmin(tot, max_range);
-        if (STEP) v += nzv;
-        if (o32) *reinterpret_cast<float *>(reinterpret_cast<char *>(o32) + (size_t)((unsigned)i * 4u)) = (float)v;
-        if (o64) *reinterpret_cast<double *>(reinterpret_cast<char *>(o64) + (size_t)((unsigned)i * 8u)) = v;
-        if (do_ttc) {
-            const double sd = v - sdv;
-            if (__builtin_expect(fabs(sd) < cand, 0)) {
-                const GroupArgs *ra = rare;
-                asm volatile("" : "+s"(ra));
-                const double proj_vel = vel * ra->s.beam_cosines[i];
-                const double ttc = sd / proj_vel;
-                if ((ttc < ra->s.ttc_thresh) && (ttc >= 0.0)) hit = true;
-            }
-        }
-    };
-
-    const double d0 = dist_lookup<IDENT, POW2>(mv, s_lut, px, py, true);
-#if defined(F110_TIMELINE)
-    { unsigned long long t = wall_clock64(); asm volatile("" : "+v"(t)); if (lane == 0) { s_tl[wave][1] = t; s_tlw[wave] = 0; } }
-    unsigned tl_wit = 0;
-#endif
-    unsigned nlook = 0;
-    if (!(d0 > eps && d0 <= max_range)) {
-        for (int i = threadIdx.x; i < nb; i += nthreads) {
-            const double2 v = STEP ? ns[i] : make_double2(0.0, 0.0);
-            emit(i, d0, v.x, v.y);
-        }
-        if (wave == 0) nlook = (unsigned)nb; // the reference reads the table once per beam
-    } else {
-        const double td = (double)a.s.scan.theta_dis;
-        double t0w = td * (yaw - a.s.scan.fov / 2.) / (2. * F110_PI);
-        t0w = fmod_small(t0w, td);
-        while (t0w < 0) t0w += td;
-        const unsigned long long T0 = (t0w >= 0 && t0w < td) ? (unsigned long long)(t0w * 1099511627776.0) : ~0ull;
-
-        bool exhausted = false; // wave-uniform: the car's queue has been handed out
-        bool active = false;
-        int beam = -1;                // the lane's beam in bits 0..11 (num_beams <= 4096) and, above them, the wave
-                                      // iteration at which it was taken (one register for both); -1: none
-        unsigned wit = 0;             // wave iterations so far (scalar)
-        double x = px, y = py, c = 0, s = 0, total = 0;
-        double nz = 0, sd = 0;
-        for (;;) {
-            const unsigned long long idle = vote(!active);
-            const int nidle = __popcll(idle);
-            int base = nb;
-            if (!exhausted) {
-                unsigned b0 = 0;
-                if (lane == 0) b0 = atomicAdd(&s_next, (unsigned)nidle);
-                base = __builtin_amdgcn_readfirstlane((int)b0);
-                exhausted = base + nidle >= nb;
-#if defined(F110_TIMELINE)
-                if (exhausted) { unsigned long long t = wall_clock64(); asm volatile("" : "+v"(t)); if (lane == 0) { s_tl[wave][1] = t; s_tlw[wave] = wit; } }
-#endif
-            }
-            if (!active) {
-                const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32),
-                                    __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
-                const int k = base + rank;
-                const bool take = k < nb;
-                const int kk = take ? k : 0;
-                const int b = s_chunk0[kk >> 6] + (kk & 63);
-                const double2 nsv = STEP ? *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(ns) + (size_t)((unsigned)b * 16u))
-                                         : make_double2(0.0, 0.0);
-                const double nzv = nz, sdv = sd;
-                const int ti = beam_theta_index(T0, t0w, b, a.s.scan);
-                const double2 cs = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(a.s.scan.cs) + (size_t)((unsigned)ti * 16u));
-                // the new beam moves in first (its loads are then dead), the old one is finished from copies: fewer
-                // registers are live in emit()'s rare division path than with the classic order
-                const int done_beam = beam;
-                const double done_total = total;
-                beam = -1;
-                if (take) {
-                    c = cs.x;
-                    s = cs.y;
-                    x = px + d0 * c;
-                    y = py + d0 * s;
-                    total = d0;
-                    beam = b | (int)(min(wit, 0x7ffffu) << 12);
-                    nz = nsv.x;
-                    sd = nsv.y;
-                    active = true;
-                }
-                if (done_beam >= 0) {
-                    if (rec) atomicMax(&s_cmax[(done_beam & 0xfff) >> 6], wit - ((unsigned)done_beam >> 12)); // (an upper bound of the ray's own iterations)
-                    emit(done_beam & 0xfff, done_total, nzv, sdv);
-                }
-            }
-            int nact = __popcll(vote(active));
-            if (nact == 0) break;
-            nlook += (unsigned)min(max(nb - base, 0), nidle); // first read of every beam taken (at the car itself)
-            const int go = exhausted ? 0 : WAVE - REFILL_MIN_IDLE;
-#if defined(F110_DRAIN_PRIO)
-            if (go == 0) __builtin_amdgcn_s_setprio(F110_DRAIN_PRIO);
-#endif
-            do {
-                nlook += (unsigned)nact;
-                wit++;
-                const double d = dist_lookup<IDENT, POW2>(mv, s_lut, x, y, active);
-                total += d;
-                x += d * c;
-                y += d * s;
-                const bool c1 = d > eps, c2 = total <= max_range;
-                active = c1 && c2;
-                nact = __popcll(vote(c1) & vote(c2));
-            } while (nact > go);
-#if defined(F110_TIMELINE)
-            tl_wit = wit;
-#endif
-        }
-    }
-    const GroupArgs *ra = rare;
-    asm volatile("" : "+s"(ra));
-    if (ra->s.lookups && lane == 0 && nlook) atomicAdd(&ra->s.lookups[car], nlook);
-#if defined(F110_TIMELINE)
-    unsigned long long tl_end = wall_clock64();
-    asm volatile("" : "+v"(tl_end));
-    if (ra->s.timeline && lane == 0) {
-        unsigned long long *tl = ra->s.timeline + ((size_t)car * nwaves + wave) * 4;
-        // group form: car | wave << 20 | nwaves << 24 | wave iterations when the queue ran dry << 28 | at the end << 46
-        tl[0] = s_tl[wave][0]; tl[1] = s_tl[wave][1]; tl[2] = tl_end;
-        tl[3] = (unsigned long long)car | ((unsigned long long)wave << 20) | ((unsigned long long)nwaves << 24) |
-                ((unsigned long long)min(s_tlw[wave], 0x3ffffu) << 28) | ((unsigned long long)min(tl_wit, 0x3ffffu) << 46);
-    }
-#endif
-    const bool whit = STEP && vote(hit) != 0ull;
-    if (STEP && !CLOSE) {
-        // the flag only; env_kernel zeroes the state.  Plain store: all writers store the same 1.
-        if (whit && lane == 0) ra->s.in_collision[car] = 1;
-    }
-    if (!CLOSE && !rec) return;
-    // ---- the last wave of the group to get here closes the car's scan: next scan's chunk order, and (CLOSE) the step
-    unsigned old = 0;
-    if (lane == 0) old = atomicAdd(&s_arrive, 1u | (whit ? 0x10000u : 0u));
-    old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
-    if ((int)(old & 0xffffu) != nwaves - 1) return;
-    if (rec) {
-        uint16_t *order = ra->order + (size_t)car * ORDER_STRIDE;
-        // rank of every FULL chunk by the longest ray life seen in it (ties: lower chunk first) = its place in the
-        // car's next queue; a trailing partial chunk keeps the last place (slot k -> beam chunk0[k >> 6] + (k & 63))
-        const int nfull = nb >> 6;
-        unsigned mine = 0, amax = 0;
-        int rank = 0;
-        if (lane < nfull) mine = s_cmax[lane];
-        for (int j = 0; j < nfull; j++) {
-            const unsigned v = s_cmax[j];
-            amax = max(amax, v);
-            rank += (lane < nfull && (v > mine || (v == mine && j < lane))) ? 1 : 0;
-        }
-        if (lane < nfull) order[rank] = (uint16_t)(lane << 6);
-        if (lane == 0) {
-            if ((nb & 63) != 0) { order[nfull] = (uint16_t)(nfull << 6); amax = max(amax, s_cmax[nfull]); }
-            order[ORDER_AGE] = (uint16_t)min(amax, 65535u);
-            order[ORDER_VALID] = 1;
-        }
-    }
-    if (!CLOSE) return;
-    if (lane != 0) return;
-    const bool anyhit = whit || (old >> 16) != 0u;
-    const FuseArgs *F = &ra->s.f;
-    double st[7];
-    // dynamics_kernel has written the new state, the FIFO and the pose snapshot, and zeroed noise_step of a pending
-    // env; nobody in this launch but this lane touches the car's state from here on
-#pragma unroll
-    for (int i = 0; i < 7; i++) st[i] = F->state[(size_t)car * 7 + i];
-    close_car_step(F, car, pend, anyhit, row, st, false);
 }
 
 // ------------------------------------------------------------------ opponents (A > 1)

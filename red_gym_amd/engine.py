@@ -118,12 +118,6 @@ class Engine(object):
             self.noise = NoiseTable(seed, self.num_beams, noise_std)
             self._upload_noise(int(noise_steps))
         self._alloc(keep_f64_scans, count_lookups)
-        forced = os.environ.get('F110_STEP_PATH')  # 'classic' | 'group[:waves]' (test suite / sweeps)
-        if forced:
-            name, _, w = forced.partition(':')
-            if name == 'closed' and self.A != 1:
-                name = 'classic'  # the closing scan exists for one agent only
-            self.set_step_path(name, int(w or 0))
 
     # ------------------------------------------------------------------ buffers
     def _alloc(self, keep_f64, count_lookups):
@@ -373,13 +367,6 @@ class Engine(object):
     def set_scan_stages(self, spec=None):
         """Wave -> car mapping of the scan launches (f110_set_scan_stages): e.g. '*:-2,6144:0,2048:2'."""
         _lib.check(self.lib.f110_set_scan_stages(self._h, None if spec is None else spec.encode()))
-
-    def set_step_path(self, path='auto', waves_per_car=0):
-        """Which kernels a step enqueues (f110_set_step_path): 'classic' = dynamics -> scan (wave per car) -> env,
-        'closed' = dynamics -> scan that also does the env bookkeeping (one agent), 'group' = one workgroup of
-        `waves_per_car` wavefronts per car, 'auto' = closed for small one-agent launches.  Results do not depend on it."""
-        code = {'auto': 0, 'classic': 1, 'group': 2, 'closed': 3}[path]
-        _lib.check(self.lib.f110_set_step_path(self._h, code, int(waves_per_car)))
 
     def launch_epoch(self):
         """Changes whenever a captured hipGraph of step() has gone stale (f110_launch_epoch)."""

@@ -14,16 +14,6 @@ def _np(t):
     return t.detach().cpu().numpy()
 
 
-@pytest.fixture(autouse=True, params=['classic', 'closed', 'group'])
-def step_path(request, monkeypatch):
-    """Every test of this module runs on all step paths (f110_set_step_path): 'classic' = dynamics_kernel ->
-    scan_kernel -> [opponents] -> env_kernel; 'closed' = dynamics_kernel -> scan_kernel that also does the env
-    bookkeeping (one agent; more agents fall back to classic); 'group' = a workgroup per car.  The engine reads
-    F110_STEP_PATH when it is built."""
-    monkeypatch.setenv('F110_STEP_PATH', request.param)
-    return request.param
-
-
 def _mk_oracle_env(assets, A, noise_steps, integrator=oracle.RK4):
     sc = oracle.Scanner(1080, 2 * np.pi)
     sc.set_map(os.path.join(assets, 'example_map.yaml'), '.png')
@@ -541,7 +531,6 @@ def test_scan_stage_lists_give_identical_results(assets, spec, A):
     acts = torch.as_tensor(workload.action_pool(8, B, A), device='cuda')
     e1 = _vec(assets, B, A, autoreset=True, count_lookups=True)
     e2 = _vec(assets, B, A, autoreset=True, count_lookups=True)
-    e1.eng.set_step_path('classic'); e2.eng.set_step_path('classic')
     e2.eng.set_scan_stages(spec)
     e1.reset(poses); e2.reset(poses)
     keys = ('scans_f64', 'scans', 'state', 'lookups', 'collisions', 'in_collision', 'toggles', 'done', 'noise_step')
@@ -554,57 +543,6 @@ def test_scan_stage_lists_give_identical_results(assets, spec, A):
             assert torch.equal(e1.eng.t[key], e2.eng.t[key]), (k, key)
     assert int(e1.eng.t['done'].sum()) >= 0 and int(e1.eng.t['lookups'].min()) > 0
     # function-level scan (pose stride 3, no noise), odd pose count
-    rng = np.random.default_rng(5)
-    ps = np.concatenate([workload.spawn_poses(37, 1)[:, 0], rng.uniform(-120, 120, (6, 3))])
-    a64, a32, alk = e1.eng.scan(ps, want_f32=True, want_lookups=True)
-    b64, b32, blk = e2.eng.scan(ps, want_f32=True, want_lookups=True)
-    assert torch.equal(a64, b64) and torch.equal(a32, b32) and torch.equal(alk, blk)
-    e1.close(); e2.close()
-
-
-@pytest.mark.parametrize('form', ['closed', 'closed:*:2', 'closed:10:0,*:3', 'group:1', 'group:2', 'group:3', 'group:4', 'group:8'])
-@pytest.mark.parametrize('A', [1, 2])
-def test_step_paths_give_identical_results(assets, form, A):
-    """The closing scan (the last wave of a car -- whole cars and cars split over 2 / 4 / 8 waves by a stage list --
-    does the env bookkeeping) and the car-group path (one workgroup of 1..8 wavefronts per car drawing beams from one
-    queue, its order learnt from the previous scan) against the classic three-kernel path: every buffer a step writes
-    `==` over 60 autoreset steps with wall hits, cars inside walls / off the map and a masked reset in between; then
-    the function-level scan."""
-    name, _, rest = form.partition(':')
-    if name == 'closed' and A != 1:
-        pytest.skip('the closing scan exists for one agent')
-    import torch
-    from red_gym_amd import workload
-    B, T = 37, 60
-    poses = workload.spawn_poses(B, A)
-    poses[3, 0, :2] = [0.0, 20.0]
-    poses[17, A - 1, :2] = [-78.0, -44.0]
-    poses[18, 0, :2] = [500.0, 500.0]
-    acts = workload.action_pool(8, B, A)
-    acts[:, 5:12, :, 0] = 0.35    # some envs steer into the wall at speed: iTTC hits, autoreset
-    acts[:, 5:12, :, 1] = 7.0
-    acts = torch.as_tensor(acts, device='cuda')
-    e1 = _vec(assets, B, A, autoreset=True, count_lookups=True)
-    e2 = _vec(assets, B, A, autoreset=True, count_lookups=True)
-    e1.eng.set_step_path('classic')
-    if name == 'group':
-        e2.eng.set_step_path('group', int(rest))
-    else:
-        e2.eng.set_step_path('closed')
-        if rest:
-            e2.eng.set_scan_stages(rest)
-    e1.reset(poses); e2.reset(poses)
-    keys = [k for k in e1.eng.t if e1.eng.t[k] is not None]
-    hits = 0
-    for k in range(T):
-        e1.step(acts[k % 8]); e2.step(acts[k % 8])
-        if k == 30:
-            m = torch.zeros(B, dtype=torch.uint8, device='cuda'); m[::3] = 1
-            e1.reset(poses, m); e2.reset(poses, m)
-        for key in keys:
-            assert torch.equal(e1.eng.t[key], e2.eng.t[key]), (k, key)
-        hits += int(e1.eng.t['done'].sum())
-    assert hits > 0
     rng = np.random.default_rng(5)
     ps = np.concatenate([workload.spawn_poses(37, 1)[:, 0], rng.uniform(-120, 120, (6, 3))])
     a64, a32, alk = e1.eng.scan(ps, want_f32=True, want_lookups=True)
@@ -661,8 +599,6 @@ def test_set_scan_stages_refuses_malformed_lists(assets):
             env.eng.set_scan_stages(bad)
     env.eng.set_scan_stages('4:1,*:0')
     env.eng.set_scan_stages(None)
-    with pytest.raises(ValueError):
-        env.eng.set_step_path('group', 9)
     env.close()
 
 

@@ -23,7 +23,6 @@ ap.add_argument('--warmup', type=int, default=40)
 a = ap.parse_args()
 B = a.envs
 env = F110VecEnv(B, map=workload.EXAMPLE_MAP, num_agents=1, autoreset=True, count_lookups=True)
-env.eng.set_step_path('classic')
 dev = env.device
 poses = torch.as_tensor(workload.spawn_poses(B, 1), device=dev)
 acts = torch.as_tensor(workload.action_pool(8, B, 1), device=dev)

@@ -16,7 +16,6 @@ ap.add_argument('--steps', type=int, default=200)
 a = ap.parse_args()
 B = a.envs
 env = F110VecEnv(B, map=workload.EXAMPLE_MAP, num_agents=1, autoreset=True)
-env.eng.set_step_path('classic')
 poses = torch.as_tensor(workload.spawn_poses(B, 1), device=env.device)
 acts = torch.as_tensor(workload.action_pool(8, B, 1), device=env.device)
 for rep in range(2):

@@ -1,6 +1,6 @@
 """Per-wave timeline of ONE step's scan / car-group launch (diagnostics build of the library):
     hipcc ... -DF110_TIMELINE -o build_variants/timeline.so ; F110_LIB=build_variants/timeline.so python tools/timeline.py
-    [--envs B] [--path classic|group:W] [--stages SPEC] [--nofuse]
+    [--envs B] [--stages SPEC]
 Prints, in microseconds from the first wave's start: when waves start (percentiles), wave lifetimes by kind (whole
 car / part of a car), the end of the launch, and how many waves are resident over time."""
 import argparse
@@ -16,7 +16,6 @@ from red_gym_amd import F110VecEnv, _lib, workload  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument('--envs', type=int, default=4096)
-ap.add_argument('--path', default='classic')
 ap.add_argument('--stages', default='')
 ap.add_argument('--warm', type=int, default=60)
 ap.add_argument('--agents', type=int, default=1)
@@ -25,8 +24,7 @@ lib = _lib.load()
 lib.f110_debug_timeline.argtypes = [C.c_void_p, C.c_int64]
 B = a.envs
 env = F110VecEnv(B, map=workload.EXAMPLE_MAP, num_agents=a.agents, autoreset=True, count_lookups=True)
-name, _, w = a.path.partition(':')
-env.eng.set_step_path(name, int(w or 0))
+name = 'classic'
 if a.stages:
     env.eng.set_scan_stages(a.stages)
 env.reset(torch.as_tensor(workload.spawn_poses(B, a.agents), device=env.device))
