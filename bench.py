@@ -82,21 +82,34 @@ def cpu_baseline(num_agents, budget_s=12.0):
 class Ranks(object):
     """One process per GPU (RANK / LOCAL_RANK / WORLD_SIZE from torch.distributed.run).
     The step path has no collective: ranks only meet at the barriers around the timed
-    region and to take the MAX of the elapsed time.  backend 'nccl' (= RCCL) on GPUs,
-    'gloo' in the CPU tests."""
+    region, to take the MAX of the elapsed time and to gather every rank's own time and
+    device name for the JSON line.  backend 'nccl' (= RCCL) on GPUs, 'gloo' in the CPU tests.
+    force_group: build the process group even for ONE rank (tests/test_gpu_rccl.py: RCCL init,
+    barrier(device_ids), all_reduce(MAX), all_gather and destroy then run on real hardware on a
+    one-GPU box -- the same calls the 8-GPU run makes)."""
 
-    def __init__(self, backend='nccl', device=None):
+    def __init__(self, backend='nccl', device=None, force_group=False):
         import torch.distributed as dist
         self.rank = int(os.environ.get('RANK', '0'))
         self.local_rank = int(os.environ.get('LOCAL_RANK', '0'))
         self.world = int(os.environ.get('WORLD_SIZE', '1'))
         self.backend, self.device, self.dist = backend, device, dist
-        if self.world > 1:
+        self.grouped = self.world > 1 or bool(force_group)
+        self.last_per_rank = None
+        if self.grouped:
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            if 'MASTER_PORT' not in os.environ:  # (only the forced one-rank group comes without a launcher)
+                import socket
+                with socket.socket() as s:
+                    s.bind(('127.0.0.1', 0))
+                    os.environ['MASTER_PORT'] = str(s.getsockname()[1])
             if backend == 'nccl':
-                dist.init_process_group('nccl', device_id=device)
+                dist.init_process_group('nccl', rank=self.rank, world_size=self.world, device_id=device)
             else:
-                dist.init_process_group(backend)
+                dist.init_process_group(backend, rank=self.rank, world_size=self.world)
+
+    def _comm_device(self):
+        return self.device if self.backend == 'nccl' else 'cpu'
 
     def sync_device(self):
         if self.device is not None:
@@ -105,23 +118,43 @@ class Ranks(object):
 
     def barrier(self):
         self.sync_device()
-        if self.world > 1:
+        if self.grouped:
             if self.backend == 'nccl':
-                self.dist.barrier(device_ids=[self.local_rank])
+                self.dist.barrier(device_ids=[self.device.index])
             else:
                 self.dist.barrier()
         self.sync_device()
 
-    def max_over_ranks(self, seconds):
-        if self.world == 1:
+    def max_over_ranks(self, seconds, own=None):
+        """MAX over ranks of `seconds` (the time between the two barriers).  `own` = this rank's time until ITS OWN work
+        was done, taken before the closing barrier: gathered from every rank into last_per_rank, so that a straggler
+        shows (after the barrier all ranks read the same clock)."""
+        own = seconds if own is None else own
+        if not self.grouped:
+            self.last_per_rank = [own]
             return seconds
         import torch
-        t = torch.tensor([seconds], dtype=torch.float64, device=self.device if self.backend == 'nccl' else 'cpu')
+        t = torch.tensor([own], dtype=torch.float64, device=self._comm_device())
+        each = [torch.zeros_like(t) for _ in range(self.world)]
+        self.dist.all_gather(each, t)
+        self.last_per_rank = [float(x.item()) for x in each]
+        t = torch.tensor([seconds], dtype=torch.float64, device=self._comm_device())
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
+    def gather_names(self, name):
+        """Every rank's device name (fixed 64-byte tensors: no pickling over the collective backend)."""
+        if not self.grouped:
+            return [name]
+        import torch
+        raw = name.encode('utf-8', 'replace')[:64].ljust(64, b'\0')
+        t = torch.tensor(list(raw), dtype=torch.uint8, device=self._comm_device())
+        each = [torch.zeros_like(t) for _ in range(self.world)]
+        self.dist.all_gather(each, t)
+        return [bytes(x.cpu().tolist()).rstrip(b'\0').decode('utf-8', 'replace') for x in each]
+
     def close(self):
-        if self.world > 1:
+        if self.grouped:
             self.barrier()
             self.dist.destroy_process_group()
 
@@ -133,8 +166,10 @@ def timed_steps(ranks, step_fn, K):
     t0 = time.perf_counter()
     for k in range(K):
         step_fn(k)
+    ranks.sync_device()
+    own = time.perf_counter() - t0      # this rank's own K steps (per_rank_ms); not what `value` is computed from
     ranks.barrier()
-    return ranks.max_over_ranks(time.perf_counter() - t0)
+    return ranks.max_over_ranks(time.perf_counter() - t0, own)
 
 
 def rank_workload(rank, B, A, pool=16):
@@ -206,11 +241,14 @@ def stub_bench(args):
     del n[:]
     elapsed = timed_steps(ranks, step_fn, args.steps)
     assert len(n) == args.steps
-    world = ranks.dist.get_world_size() if ranks.world > 1 else 1
+    per_rank = list(ranks.last_per_rank)
+    names = ranks.gather_names('stub-cpu-%d' % ranks.rank)
+    world = ranks.dist.get_world_size() if ranks.grouped else 1
     out = {'metric': 'env steps/sec (all envs), 1080-beam lidar', 'value': world * args.envs * args.steps / elapsed,
            'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
            'vs_baseline': None, 'dtype': 'f64', 'data': 'stub',
+           'per_rank_ms': [t / args.steps * 1e3 for t in per_rank], 'devices': names,
            'config': {'workload': 'STUB step (sleep), rank plumbing only', 'envs_per_gpu': args.envs,
                       'agents': args.agents, 'shard_checksum': float(poses.sum() + acts.sum())},
            'roofline': None}
@@ -240,6 +278,9 @@ def main(argv=None):
     ap.add_argument('--sustained', type=int, default=200,
                     help='after the timed region, time this many further steps (clocks up, cars scattered) and report '
                          'them as `sustained` beside `value` (0 = skip); never part of `value`')
+    ap.add_argument('--repeats', type=int, default=1,
+                    help='R > 1: after the protocol region (which alone gives `value`), R - 1 further timed regions of K steps '
+                         'each; the median of all R is reported beside it as `median_of_repeats` (SURVEY 8d: median of 5)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-scan-events', action='store_true',
                     help='do not bracket the scan kernel with hipEvents (roofline becomes null)')
@@ -268,9 +309,11 @@ def main(argv=None):
         sys.exit('bench.py: rank with LOCAL_RANK=%d but only %d GPU(s) are visible' % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    ranks = Ranks(os.environ.get('F110_BENCH_BACKEND', 'nccl'), dev)
+    # F110_BENCH_FORCE_GROUP=1 (tests/test_gpu_rccl.py): a ONE-rank RCCL process group, so that the collective calls of the
+    # multi-GPU run execute on a one-GPU box
+    ranks = Ranks(os.environ.get('F110_BENCH_BACKEND', 'nccl'), dev, force_group=os.environ.get('F110_BENCH_FORCE_GROUP') == '1')
     rank = ranks.rank
-    world = ranks.dist.get_world_size() if ranks.world > 1 else 1  # as the process group reports it
+    world = ranks.dist.get_world_size() if ranks.grouped else 1  # as the process group reports it
     if world != args.gpus and rank == 0:
         sys.stderr.write('bench.py: --gpus %d but the launcher started %d rank(s); reporting n_gpus=%d\n'
                          % (args.gpus, world, world))
@@ -325,10 +368,22 @@ def main(argv=None):
     else:
         env.eng.profile_begin(1, every=NEVER)
     elapsed = timed_steps(ranks, step_fn, K)
+    per_rank = list(ranks.last_per_rank)                                      # every rank's own elapsed seconds
     scan_prof = env.eng.profile_end()                                         # the sampled launches of the K timed steps only
     if args.no_scan_events:
         scan_prof = None
     tot_lookups = int(lookups.to(torch.int64).sum().item())                  # ... and their table reads
+    repeats = None
+    if args.repeats > 1:
+        env.eng.profile_begin(1, every=NEVER)
+        ms = [elapsed / K * 1e3]
+        for r in range(1, args.repeats):
+            ms.append(timed_steps(ranks, lambda k, r=r: step_fn(r * K + k), K) / K * 1e3)
+        env.eng.profile_end()
+        med = float(np.median(ms))
+        repeats = {'ms_per_step': ms, 'median_ms_per_step': med, 'value': world * B / (med * 1e-3), 'unit': 'env-steps/s',
+                   'note': 'region 0 is the protocol region (`value`); regions 1.. follow it back to back, uninstrumented'}
+    names = ranks.gather_names(torch.cuda.get_device_name(dev))
     sustained = None
     if args.sustained > 0:
         env.eng.profile_begin(1, every=NEVER)                                # uninstrumented, like the un-sampled timed steps
@@ -364,15 +419,17 @@ def main(argv=None):
             # `achieved` / `frac` are SURVEY 8(d)'s MODEL: algorithmic bytes (4 B per distance-table lookup + the fp32
             # scan + state) over the kernel time, priced against HBM peak as the survey prescribes.  What the
             # counters say is spelled out beside it: the lookups are served by L1 / L2, real HBM traffic is the
-            # scan write (measured_hbm_*), and the kernel is bound by VALU issue and L1->L2 gather traffic.
+            # scan write (traffic_*), and the kernel is bound by VALU issue and L1->L2 gather traffic.
             roof = {'bound': 'hbm', 'kernel': 'scan_kernel', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                     'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                    'traffic_source': 'profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an EARLIER run of '
+                                      'this workload, tools/profile.sh; not collected by this run)' if traffic else None,
                     'avg_launch_ms': avg_s * 1e3, 'launches': n_launch,
                     'lookups_per_car_step': tot_lookups / max(n_launch, 1) / cars, 'events_every': max(1, args.scan_events_every),
                     'algorithmic_bytes_per_launch': bytes_per_launch,
                     'model': 'SURVEY 8(d) algorithmic bytes: lookups*4 + cars*(1080*4 + 72), not HBM traffic',
-                    'measured_hbm_gbs': (traffic / avg_s / 1e9) if traffic else None,
-                    'measured_hbm_frac': (traffic / avg_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                    'traffic_gbs': (traffic / avg_s / 1e9) if traffic else None,
+                    'traffic_frac': (traffic / avg_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
                     'limiter': 'VALU issue (~81 % of SIMD slots busy) and L1->L2 gather traffic (~10 TB/s of '
                                'TCP->TCC reads); see DESIGN.md 5 and profiles/r02*'}
         out = {'metric': 'env steps/sec (all envs), 1080-beam lidar', 'value': value, 'unit': 'env-steps/s',
@@ -386,7 +443,10 @@ def main(argv=None):
                                          + ('' if args.bitmap == 'none' else '; + %s bitmap of every ego scan' % args.bitmap)),
                           'envs_per_gpu': B, 'agents': A, 'num_beams': 1080, 'map': 'example_map',
                           'sharding': 'independent env shards, no collective on the step path'},
+               'per_rank_ms': [t / K * 1e3 for t in per_rank], 'devices': names,
                'roofline': roof, 'sustained': sustained}
+        if repeats:
+            out['median_of_repeats'] = repeats
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(A)
     env.close()

@@ -17,7 +17,12 @@
  *     read during the call and not retained.  Nothing is allocated in
  *     f110_step/f110_reset; kernels are enqueued on `stream` (a hipStream_t
  *     passed as void*, NULL = default stream) and the call does not synchronise.
- *   - a handle is bound to one device and is not thread-safe.
+ *   - a handle is bound to one device and is not thread-safe.  Calls that allocate or upload (f110_create, map
+ *     installs, table uploads, f110_graph_create, f110_destroy ...) make the handle's device current for their own
+ *     duration and RESTORE the caller's current device before returning.  Calls that launch on the caller's stream
+ *     (f110_step, f110_reset, f110_graph_launch, the function-level entry points, f110_bitmap_render) do not switch:
+ *     the stream belongs to the calling thread's current device, so that must be the handle's -- otherwise
+ *     F110_E_INVALID.  Several handles (on one device or on several) may be driven from one process.
  *   - there is no f110_get_state / f110_set_state: the whole simulation state lives in the CALLER-owned
  *     buffers of the f110_buffers struct, bound once with f110_bind, so reading, checkpointing or overwriting the state is
  *     an ordinary access to the caller's own memory between steps (F110VecEnv.state_dict / load_state_dict).

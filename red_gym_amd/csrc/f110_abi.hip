@@ -41,6 +41,30 @@ static int fail(int code, const char *fmt, ...)
             return fail(F110_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
+// Makes `dev` the calling thread's current device for the scope of one library call and restores the caller's own
+// afterwards: a process that drives several GPUs (or several handles on different GPUs) keeps ITS current device across
+// every call.  f110_step / f110_reset and the function-level entry points do not switch -- they launch on the caller's
+// stream, which belongs to the caller's current device -- they check (check_device) and refuse a mismatch.
+struct DeviceScope {
+    int prev = -1;
+    bool switched = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceScope(int dev)
+    {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != dev) {
+            err = hipSetDevice(dev);
+            switched = err == hipSuccess;
+        }
+    }
+    ~DeviceScope() { if (switched) (void)hipSetDevice(prev); }
+    DeviceScope(const DeviceScope &) = delete;
+    DeviceScope &operator=(const DeviceScope &) = delete;
+};
+#define ON_DEVICE(dev)            \
+    DeviceScope dev_scope_(dev);  \
+    HIP_TRY(dev_scope_.err)
+
 struct f110_handle {
     f110_config cfg;
     Params params;                    // Simulator.params: the constructor's (GJK vertices, base_classes.py:542)
@@ -274,7 +298,7 @@ extern "C" int f110_create(const f110_config *cfg, f110_handle **out)
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (cfg->device < 0 || cfg->device >= ndev)
         return fail(F110_E_HIP, "f110_create: device %d not available (%d HIP devices)", cfg->device, ndev);
-    HIP_TRY(hipSetDevice(cfg->device));
+    ON_DEVICE(cfg->device);
     f110_handle *h = new (std::nothrow) f110_handle();
     if (!h) return fail(F110_E_INVALID, "f110_create: out of host memory");
     h->cfg = *cfg;
@@ -305,7 +329,7 @@ extern "C" int f110_create(const f110_config *cfg, f110_handle **out)
 extern "C" void f110_destroy(f110_handle *h)
 {
     if (!h) return;
-    (void)hipSetDevice(h->cfg.device);
+    DeviceScope on_dev(h->cfg.device);
     void *ptrs[] = {h->d_cs, h->d_beam_cs, h->d_noise_side, h->d_scan_angles, h->d_beam_cosines, h->d_side,
                     h->d_chunk0, h->d_agent_params, h->d_opp_pairs, h->d_maps, h->d_env_map};
     for (void *p : ptrs)
@@ -330,7 +354,7 @@ extern "C" int f110_update_params(f110_handle *h, const double *p, int32_t agent
 {
     if (!h || !p) return fail(F110_E_INVALID, "f110_update_params: null argument");
     if (agent_idx >= h->cfg.num_agents) return fail(F110_E_INDEX, "Index given is out of bounds for list of agents.");
-    HIP_TRY(hipSetDevice(h->cfg.device));
+    ON_DEVICE(h->cfg.device);
     for (int i = 0; i < h->cfg.num_agents; i++)
         if (agent_idx < 0 || agent_idx == i) memcpy(h->agent_params[i].v, p, sizeof(double) * P_COUNT);
     return upload_agent_params(h);
@@ -340,7 +364,7 @@ extern "C" int f110_set_tables(f110_handle *h, const double *sines, const double
                                const double *bcos, const double *side)
 {
     if (!h) return fail(F110_E_INVALID, "f110_set_tables: null handle");
-    HIP_TRY(hipSetDevice(h->cfg.device));
+    ON_DEVICE(h->cfg.device);
     HIP_TRY(hipDeviceSynchronize()); // enqueued steps may still read the tables being replaced
     int rc = F110_OK;
     if (sines) h->h_sines.assign(sines, sines + h->cfg.theta_dis);
@@ -431,7 +455,7 @@ static int install_map(f110_handle *h, int slot, const double *dt, const uint32_
         cells[t] = (uint16_t)(rank < SLOT_FAR ? 8 * rank : OFF_FAR);
         cells_far[t] = (uint16_t)rank;
     }
-    HIP_TRY(hipSetDevice(h->cfg.device));
+    ON_DEVICE(h->cfg.device);
     HIP_TRY(hipDeviceSynchronize()); // the previous map may still be in use by enqueued steps
     if (sl.d_cells) { (void)hipFree(sl.d_cells); sl.d_cells = nullptr; }
     if (sl.d_cells_far) { (void)hipFree(sl.d_cells_far); sl.d_cells_far = nullptr; }
@@ -511,7 +535,7 @@ static int install_map_occupancy_dev(f110_handle *h, int slot, const uint8_t *ma
     const size_t n = (size_t)H * W;
     const int strips = (W >> 3) + 2, Hp = ((H + 2 + 7) >> 3) << 3; // strip 0 only holds the left border column
     const size_t n_tiled = (size_t)strips * Hp * 8;
-    HIP_TRY(hipSetDevice(h->cfg.device));
+    ON_DEVICE(h->cfg.device);
     HIP_TRY(hipDeviceSynchronize()); // the previous map may still be in use by enqueued steps
     hipStream_t st = nullptr;
     DevTemp tmp;
@@ -601,7 +625,7 @@ extern "C" int f110_set_map_slot_occupancy(f110_handle *h, int32_t slot, const u
         return rc;
     const size_t n = (size_t)H * W;
     if (!memchr(mask, 0, n)) return fail(F110_E_INVALID, "f110_set_map_occupancy: map has no occupied cell");
-    HIP_TRY(hipSetDevice(h->cfg.device));
+    ON_DEVICE(h->cfg.device);
     DevTemp tmp;
     uint8_t *mask_dev = nullptr;
     HIP_TRY(tmp.alloc(&mask_dev, n));
@@ -646,7 +670,7 @@ extern "C" int f110_get_map_slot_dt(f110_handle *h, int32_t slot, double *out)
     if (!out) return fail(F110_E_INVALID, "f110_get_map_slot_dt: null argument");
     const f110_handle::MapSlot &sl = h->slots[slot];
     if (!sl.used) return fail(F110_E_NOMAP, "Map is not set for scan simulator.");
-    HIP_TRY(hipSetDevice(h->cfg.device));
+    ON_DEVICE(h->cfg.device);
     HIP_TRY(hipMemcpy(out, sl.d_dt, (size_t)sl.dev.H * sl.dev.W * sizeof(double), hipMemcpyDeviceToHost));
     return F110_OK;
 }
@@ -678,7 +702,7 @@ extern "C" int f110_assign_maps(f110_handle *h, const int32_t *map_of_env)
                     return fail(F110_E_INVALID, "f110_assign_maps: cars %d and %d share a scan workgroup but not a map "
                                 "(give every map a block of envs whose car count is a multiple of %d)", c, c + j, SCAN_WAVES);
     }
-    HIP_TRY(hipSetDevice(h->cfg.device));
+    ON_DEVICE(h->cfg.device);
     HIP_TRY(hipDeviceSynchronize()); // enqueued steps may still read the table
     if (!h->d_env_map) HIP_TRY(hipMalloc((void **)&h->d_env_map, sizeof(int32_t) * B));
     HIP_TRY(hipMemcpy(h->d_env_map, m.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice));
@@ -692,7 +716,7 @@ extern "C" int f110_set_noise_table(f110_handle *h, const double *tbl, int64_t T
 {
     if (!h) return fail(F110_E_INVALID, "f110_set_noise_table: null handle");
     if (T < 0 || (T > 0 && !tbl)) return fail(F110_E_INVALID, "f110_set_noise_table: bad table");
-    HIP_TRY(hipSetDevice(h->cfg.device));
+    ON_DEVICE(h->cfg.device);
     HIP_TRY(hipDeviceSynchronize());
     h->h_noise.clear();
     if (T > 0) h->h_noise.assign(tbl, tbl + (size_t)T * h->cfg.num_beams);
@@ -711,7 +735,7 @@ static int rebuild_noise_side(f110_handle *h)
             ns[(size_t)t * nb + i].x = T > 0 ? h->h_noise[(size_t)t * nb + i] : 0.0;
             ns[(size_t)t * nb + i].y = h->h_side[i];
         }
-    HIP_TRY(hipSetDevice(h->cfg.device));
+    ON_DEVICE(h->cfg.device);
     HIP_TRY(hipDeviceSynchronize()); // enqueued steps may still read the old table
     if (h->d_noise_side) { (void)hipFree(h->d_noise_side); h->d_noise_side = nullptr; }
     HIP_TRY(hipMalloc((void **)&h->d_noise_side, ns.size() * sizeof(double2)));
@@ -1038,9 +1062,26 @@ static int run_step(f110_handle *h, const double *actions, int reset_only, const
     return emit(st, (const void *)&env_kernel, dim3((c.num_envs + 127) / 128), dim3(128), 0, e);
 }
 
-static int check_ready(f110_handle *h, const char *who)
+// Launches go to the caller's stream, which belongs to the calling thread's CURRENT device: it must be the handle's.
+// (Checked, not switched: hipGetDevice is a thread-local read; switching would cost two runtime calls per step and
+// still leave the caller's stream on the wrong device.)
+static int check_current_device(int dev, const char *who)
+{
+    int cur = -1;
+    HIP_TRY(hipGetDevice(&cur));
+    if (cur != dev)
+        return fail(F110_E_INVALID, "%s: the handle lives on device %d but the calling thread's current device is %d; make the "
+                    "handle's device current (hipSetDevice / torch.cuda.device) and pass a stream of that device", who, dev, cur);
+    return F110_OK;
+}
+
+static int check_device(const f110_handle *h, const char *who) { return check_current_device(h->cfg.device, who); }
+
+static int check_ready(f110_handle *h, const char *who, bool launches_on_callers_stream = true)
 {
     if (!h) return fail(F110_E_INVALID, "%s: null handle", who);
+    if (launches_on_callers_stream)
+        if (int rc = check_device(h, who)) return rc;
     if (!h->has_map) return fail(F110_E_NOMAP, "Map is not set for scan simulator.");
     if (!h->bound) return fail(F110_E_UNBOUND, "%s: f110_bind has not been called", who);
     return F110_OK;
@@ -1096,7 +1137,7 @@ struct f110_graph {
 extern "C" void f110_graph_destroy(f110_graph *g)
 {
     if (!g) return;
-    if (g->h) (void)hipSetDevice(g->h->cfg.device);
+    DeviceScope on_dev(g->h ? g->h->cfg.device : 0);
     if (g->exec) (void)hipGraphExecDestroy(g->exec);
     if (g->graph) (void)hipGraphDestroy(g->graph);
     if (g->cap) (void)hipStreamDestroy(g->cap);
@@ -1105,11 +1146,11 @@ extern "C" void f110_graph_destroy(f110_graph *g)
 
 extern "C" int f110_graph_create(f110_handle *h, const double *actions, int32_t how, f110_graph **out)
 {
-    int rc = check_ready(h, "f110_graph_create");
+    int rc = check_ready(h, "f110_graph_create", false); // builds on the handle's device itself (ON_DEVICE below)
     if (rc) return rc;
     if (!actions || !out) return fail(F110_E_INVALID, "f110_graph_create: null argument");
     if (how != F110_GRAPH_NODES && how != F110_GRAPH_CAPTURE) return fail(F110_E_INVALID, "f110_graph_create: how = %d (0 kernel nodes, 1 stream capture)", how);
-    HIP_TRY(hipSetDevice(h->cfg.device));
+    ON_DEVICE(h->cfg.device);
     f110_graph *g = new (std::nothrow) f110_graph;
     if (!g) return fail(F110_E_INVALID, "f110_graph_create: out of host memory");
     g->h = h; g->epoch = h->epoch;
@@ -1166,6 +1207,7 @@ extern "C" int f110_graph_launch(f110_graph *g, void *stream)
         return fail(F110_E_INVALID, "f110_graph_launch: the graph is stale (a table, map, binding or launch setting of the handle "
                                     "changed since f110_graph_create: f110_launch_epoch moved from %lld to %lld); create it again",
                     (long long)g->epoch, (long long)g->h->epoch);
+    if (int rc = check_device(g->h, "f110_graph_launch")) return rc;
     HIP_TRY(hipGraphLaunch(g->exec, (hipStream_t)stream));
     return F110_OK;
 }
@@ -1221,7 +1263,7 @@ extern "C" int f110_profile_every(f110_handle *h, int32_t every)
 extern "C" int f110_profile_begin(f110_handle *h, int32_t max_launches)
 {
     if (!h || max_launches < 1 || max_launches > (1 << 20)) return fail(F110_E_INVALID, "f110_profile_begin: bad arguments");
-    HIP_TRY(hipSetDevice(h->cfg.device));
+    ON_DEVICE(h->cfg.device);
     prof_clear(h);
     h->prof_seq = 0;
     h->prof_ev.resize((size_t)2 * max_launches);
@@ -1285,9 +1327,10 @@ extern "C" int f110_pure_pursuit(f110_handle *h, const double *waypoints, int32_
                                  double wheelbase, double max_reacquire, const double *state, int32_t n,
                                  double *actions, void *stream)
 {
-    (void)h; // stateless: the handle is optional (NULL: the launch goes to the calling thread's current device)
+    // stateless: the handle is optional (NULL: the launch goes to the calling thread's current device)
     if (n < 0) return fail(F110_E_INVALID, "f110_pure_pursuit: bad arguments");
     if (n == 0) return F110_OK;
+    if (h) if (int rc = check_device(h, "f110_pure_pursuit")) return rc;
     if (!waypoints || !state || !actions) return fail(F110_E_INVALID, "f110_pure_pursuit: null pointer");
     if (M < 2) return fail(F110_E_INVALID, "f110_pure_pursuit: M=%d waypoints (a raceline has at least 2)", M);
     int dev = 0;
@@ -1333,8 +1376,8 @@ extern "C" int f110_pure_pursuit_tracks(f110_handle *h, const double *waypoints,
                                         double vgain, double wheelbase, double max_reacquire, const double *state, int32_t n,
                                         double *actions, double *workspace, int32_t boxes_valid, void *stream)
 {
-    (void)h;
     if (n < 0 || K < 1) return fail(F110_E_INVALID, "f110_pure_pursuit_tracks: bad arguments (n=%d, K=%d)", n, K);
+    if (h) if (int rc = check_device(h, "f110_pure_pursuit_tracks")) return rc;
     if (!waypoints || !offsets_dev || !offsets_host || !workspace) return fail(F110_E_INVALID, "f110_pure_pursuit_tracks: null pointer");
     int max_m = 0;
     if (offsets_host[0] != 0) return fail(F110_E_INVALID, "f110_pure_pursuit_tracks: offsets[0] must be 0");
@@ -1368,6 +1411,7 @@ extern "C" int f110_scan(f110_handle *h, const double *poses, int32_t n, double 
     if (!h->has_map) return fail(F110_E_NOMAP, "Map is not set for scan simulator.");
     if (n == 0) return F110_OK;
     if (!poses || (!out64 && !out32)) return fail(F110_E_INVALID, "f110_scan: null pose or output pointer");
+    if (int rc = check_device(h, "f110_scan")) return rc;
     ScanArgs s;
     memset(&s, 0, sizeof(s));
     s.maps = h->d_maps; s.scan = scan_dev(h); s.n_cars = n; s.agents = 1;
@@ -1384,6 +1428,7 @@ extern "C" int f110_update_pose(f110_handle *h, double *state, double *steer_buf
     if (h && n == 0) return F110_OK;
     if (!h || !state || !steer_buf || !steer_cnt || !actions || n < 0)
         return fail(F110_E_INVALID, "f110_update_pose: bad arguments");
+    if (int rc = check_device(h, "f110_update_pose")) return rc;
     DynArgs d;
     memset(&d, 0, sizeof(d));
     d.n_cars = n; d.agents = 1; d.state = state; d.steer_buf = steer_buf; d.steer_cnt = steer_cnt; d.actions = actions;
@@ -1398,6 +1443,7 @@ extern "C" int f110_vehicle_dynamics(f110_handle *h, const double *x, const doub
 {
     if (h && n == 0) return F110_OK;
     if (!h || !x || !u || !f || n < 0) return fail(F110_E_INVALID, "f110_vehicle_dynamics: bad arguments");
+    if (int rc = check_device(h, "f110_vehicle_dynamics")) return rc;
     hipLaunchKernelGGL(rhs_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, u, n, kinematic,
                        h->d_agent_params, f);
     HIP_TRY(hipGetLastError());
@@ -1408,6 +1454,7 @@ extern "C" int f110_get_vertices(f110_handle *h, const double *poses, int32_t n,
 {
     if (h && n == 0) return F110_OK;
     if (!h || !poses || !verts || n < 0) return fail(F110_E_INVALID, "f110_get_vertices: bad arguments");
+    if (int rc = check_device(h, "f110_get_vertices")) return rc;
     hipLaunchKernelGGL(vertices_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, poses, n,
                        h->params.v[P_LENGTH], h->params.v[P_WIDTH], verts);
     HIP_TRY(hipGetLastError());
@@ -1418,6 +1465,7 @@ extern "C" int f110_gjk_pairs(f110_handle *h, const double *va, const double *vb
 {
     if (h && n == 0) return F110_OK;
     if (!h || !va || !vb || !hit || n < 0) return fail(F110_E_INVALID, "f110_gjk_pairs: bad arguments");
+    if (int rc = check_device(h, "f110_gjk_pairs")) return rc;
     hipLaunchKernelGGL(gjk_pairs_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, va, vb, n, hit);
     HIP_TRY(hipGetLastError());
     return F110_OK;
@@ -1428,6 +1476,7 @@ extern "C" int f110_collision_multiple(f110_handle *h, const double *verts, int3
 {
     if (h && n == 0) return F110_OK;
     if (!h || !verts || !col || !cidx || n < 0 || A < 1) return fail(F110_E_INVALID, "f110_collision_multiple: bad arguments");
+    if (int rc = check_device(h, "f110_collision_multiple")) return rc;
     hipLaunchKernelGGL(collision_multiple_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, verts, n, A,
                        col, cidx);
     HIP_TRY(hipGetLastError());
@@ -1439,6 +1488,7 @@ extern "C" int f110_check_ttc(f110_handle *h, const double *scans, const double 
 {
     if (h && n == 0) return F110_OK;
     if (!h || !scans || !vel || !hit || n < 0) return fail(F110_E_INVALID, "f110_check_ttc: bad arguments");
+    if (int rc = check_device(h, "f110_check_ttc")) return rc;
     hipLaunchKernelGGL(ttc_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, scans, vel, n, h->cfg.num_beams,
                        h->d_beam_cosines, h->d_side, h->cfg.ttc_thresh, hit);
     HIP_TRY(hipGetLastError());
@@ -1450,6 +1500,7 @@ extern "C" int f110_ray_cast(f110_handle *h, const double *ego, const double *ve
 {
     if (h && n == 0) return F110_OK;
     if (!h || !ego || !verts || !scans || n < 0) return fail(F110_E_INVALID, "f110_ray_cast: bad arguments");
+    if (int rc = check_device(h, "f110_ray_cast")) return rc;
     hipLaunchKernelGGL(ray_cast_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, ego, verts, n,
                        h->cfg.num_beams, h->d_scan_angles, h->d_beam_cs, scans, span);
     HIP_TRY(hipGetLastError());
@@ -1489,7 +1540,7 @@ struct f110_bitmap {
 extern "C" void f110_bitmap_destroy(f110_bitmap *b)
 {
     if (!b) return;
-    (void)hipSetDevice(b->cfg.device);
+    DeviceScope on_dev(b->cfg.device);
     if (b->d_idx) (void)hipFree(b->d_idx);
     if (b->d_cos) (void)hipFree(b->d_cos);
     if (b->d_sin) (void)hipFree(b->d_sin);
@@ -1517,7 +1568,8 @@ extern "C" int f110_bitmap_create(const f110_bitmap_config *cfg, const int32_t *
     f110_bitmap *b = new (std::nothrow) f110_bitmap;
     if (!b) return fail(F110_E_INVALID, "out of memory");
     b->cfg = *cfg; b->S = S; b->lds = lds;
-    if (hipSetDevice(cfg->device) != hipSuccess) { delete b; return fail(F110_E_HIP, "hipSetDevice(%d) failed", cfg->device); }
+    DeviceScope on_dev(cfg->device);
+    if (on_dev.err != hipSuccess) { delete b; return fail(F110_E_HIP, "hipSetDevice(%d) failed", cfg->device); }
     hipError_t e = hipMalloc((void **)&b->d_idx, T * sizeof(int32_t));
     if (e == hipSuccess) e = hipMalloc((void **)&b->d_cos, T * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void **)&b->d_sin, T * sizeof(double));
@@ -1539,6 +1591,7 @@ extern "C" int f110_bitmap_render(f110_bitmap *b, const void *scans, int32_t sca
     if (!scans || !out) return fail(F110_E_INVALID, "f110_bitmap_render: null pointer");
     if (stride < b->cfg.num_beams || n > 0x7fffffff) return fail(F110_E_INVALID, "f110_bitmap_render: stride %lld < num_beams or n too large", (long long)stride);
     if ((uintptr_t)out % 16) return fail(F110_E_INVALID, "f110_bitmap_render: out must be 16-byte aligned");
+    if (int rc = check_current_device(b->cfg.device, "f110_bitmap_render")) return rc;
     BitmapArgs a;
     a.scans = scans; a.is_f64 = scans_f64 != 0; a.stride = stride; a.n = (int)n;
     a.idx = b->d_idx; a.cosv = b->d_cos; a.sinv = b->d_sin; a.T = b->cfg.target_beam_count;
@@ -1557,6 +1610,7 @@ extern "C" int f110_bitmap_points(f110_bitmap *b, const void *scans, int32_t sca
     if (n == 0) return F110_OK;
     if (!scans || !points) return fail(F110_E_INVALID, "f110_bitmap_points: null pointer");
     if (stride < b->cfg.num_beams || n > 0x7fffffff) return fail(F110_E_INVALID, "f110_bitmap_points: stride %lld < num_beams or n too large", (long long)stride);
+    if (int rc = check_current_device(b->cfg.device, "f110_bitmap_points")) return rc;
     BitmapArgs a;
     memset(&a, 0, sizeof(a));
     a.scans = scans; a.is_f64 = scans_f64 != 0; a.stride = stride; a.n = (int)n;

@@ -73,6 +73,19 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
+def on_own_device(method):
+    """The library launches on the caller's stream and refuses a handle whose device is not the calling thread's
+    current one (f110_hip.h, conventions): every launching method runs with the engine's device current, so that
+    engines on different GPUs -- or next to the caller's own work on another GPU -- can share a process."""
+    import functools
+
+    @functools.wraps(method)
+    def wrapper(self, *args, **kwargs):
+        with torch.cuda.device(self.device):
+            return method(self, *args, **kwargs)
+    return wrapper
+
+
 def _np_ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
@@ -234,6 +247,7 @@ class Engine(object):
             self.params = dict(params)
 
     # ------------------------------------------------------------------ step path
+    @on_own_device
     def reset(self, poses, mask=None):
         """poses: [B,A,3] float64 tensor on the device; mask: [B] uint8 tensor or None."""
         if tuple(poses.shape) != (self.B, self.A, 3):
@@ -247,6 +261,7 @@ class Engine(object):
         self.host_steps_bound += 1
         self._keep = (poses, mask)  # keep inputs alive until the stream has consumed them
 
+    @on_own_device
     def step(self, actions):
         """actions: [B,A,2] float64 tensor on the device (steer, speed)."""
         if tuple(actions.shape) != (self.B, self.A, 2):
@@ -264,6 +279,7 @@ class Engine(object):
         t = t.to(device=self.device, dtype=torch.float64).contiguous()
         return t.reshape(shape) if shape is not None else t
 
+    @on_own_device
     def scan(self, poses, want_f32=False, want_lookups=False):
         poses = self._dev64(poses, (-1, 3))
         n = poses.shape[0]
@@ -278,6 +294,7 @@ class Engine(object):
             res.append(lk)
         return res[0] if len(res) == 1 else tuple(res)
 
+    @on_own_device
     def update_pose(self, state, steer_buf, steer_cnt, actions):
         state, steer_buf = self._dev64(state, (-1, 7)).clone(), self._dev64(steer_buf, (-1, 2)).clone()
         cnt = torch.as_tensor(np.asarray(steer_cnt)).to(device=self.device, dtype=torch.int32).contiguous().clone()
@@ -286,6 +303,7 @@ class Engine(object):
                                              state.shape[0], self._stream()))
         return state, steer_buf, cnt
 
+    @on_own_device
     def vehicle_dynamics(self, x, u, kinematic=False):
         """dynamic_models.py:124-176 (or :91-121): f(x, u) with agent 0's parameters."""
         x, u = self._dev64(x, (-1, 7)), self._dev64(u, (-1, 2))
@@ -294,18 +312,21 @@ class Engine(object):
                                                   self._stream()))
         return f
 
+    @on_own_device
     def get_vertices(self, poses):
         poses = self._dev64(poses, (-1, 3))
         out = torch.empty((poses.shape[0], 4, 2), dtype=torch.float64, device=self.device)
         _lib.check(self.lib.f110_get_vertices(self._h, _ptr(poses), poses.shape[0], _ptr(out), self._stream()))
         return out
 
+    @on_own_device
     def gjk_pairs(self, va, vb):
         va, vb = self._dev64(va, (-1, 4, 2)), self._dev64(vb, (-1, 4, 2))
         hit = torch.zeros((va.shape[0],), dtype=torch.uint8, device=self.device)
         _lib.check(self.lib.f110_gjk_pairs(self._h, _ptr(va), _ptr(vb), va.shape[0], _ptr(hit), self._stream()))
         return hit
 
+    @on_own_device
     def collision_multiple(self, verts):
         verts = self._dev64(verts)
         n, A = verts.shape[0], verts.shape[1]
@@ -314,12 +335,14 @@ class Engine(object):
         _lib.check(self.lib.f110_collision_multiple(self._h, _ptr(verts), n, A, _ptr(col), _ptr(idx), self._stream()))
         return col, idx
 
+    @on_own_device
     def check_ttc(self, scans, vel):
         scans, vel = self._dev64(scans, (-1, self.num_beams)), self._dev64(vel, (-1,))
         hit = torch.zeros((scans.shape[0],), dtype=torch.uint8, device=self.device)
         _lib.check(self.lib.f110_check_ttc(self._h, _ptr(scans), _ptr(vel), scans.shape[0], _ptr(hit), self._stream()))
         return hit
 
+    @on_own_device
     def ray_cast(self, ego_poses, opp_verts, scans):
         ego, verts = self._dev64(ego_poses, (-1, 3)), self._dev64(opp_verts, (-1, 4, 2))
         scans = self._dev64(scans, (-1, self.num_beams)).clone()
@@ -329,6 +352,7 @@ class Engine(object):
         return scans, span
 
     # ------------------------------------------------------------------ planner
+    @on_own_device
     def pure_pursuit(self, waypoints, lookahead, vgain, wheelbase=0.17145 + 0.15875, max_reacquire=20.,
                      state=None, out=None):
         """waypoints: [M,3] (x, y, speed) device tensor; returns actions [B,A,2] (steer, speed)
@@ -340,13 +364,13 @@ class Engine(object):
         if not (torch.is_tensor(waypoints) and waypoints.device == self.device and waypoints.dtype == torch.float64
                 and waypoints.is_contiguous()):
             waypoints = self._dev64(waypoints, (-1, 3))
-        with torch.cuda.device(self.device):  # the launch goes to the CURRENT device's stream table
-            _lib.check(self.lib.f110_pure_pursuit(self._h, _ptr(waypoints), waypoints.shape[0], float(lookahead),
-                                                  float(vgain), float(wheelbase), float(max_reacquire), _ptr(st), n,
-                                                  _ptr(out), self._stream()))
+        _lib.check(self.lib.f110_pure_pursuit(self._h, _ptr(waypoints), waypoints.shape[0], float(lookahead),
+                                              float(vgain), float(wheelbase), float(max_reacquire), _ptr(st), n,
+                                              _ptr(out), self._stream()))
         self._keep_wp = waypoints
         return out.view(self.B, self.A, 2) if state is None else out
 
+    @on_own_device
     def pure_pursuit_tracks(self, tracks, track_of_car, lookahead, vgain, wheelbase=0.17145 + 0.15875, max_reacquire=20.,
                             state=None, out=None):
         """Pure pursuit when cars drive on different racelines (one launch): `tracks` a TrackSet, `track_of_car` an
@@ -355,11 +379,10 @@ class Engine(object):
         n = st.numel() // 7
         if out is None:
             out = torch.empty((n, 2), dtype=torch.float64, device=self.device)
-        with torch.cuda.device(self.device):
-            _lib.check(self.lib.f110_pure_pursuit_tracks(self._h, _ptr(tracks.waypoints), _ptr(tracks.offsets_dev),
-                                                         _np_ptr(tracks.offsets), tracks.K, _ptr(track_of_car), float(lookahead),
-                                                         float(vgain), float(wheelbase), float(max_reacquire), _ptr(st), n, _ptr(out),
-                                                         _ptr(tracks.workspace), int(tracks.boxes_valid), self._stream()))
+        _lib.check(self.lib.f110_pure_pursuit_tracks(self._h, _ptr(tracks.waypoints), _ptr(tracks.offsets_dev),
+                                                     _np_ptr(tracks.offsets), tracks.K, _ptr(track_of_car), float(lookahead),
+                                                     float(vgain), float(wheelbase), float(max_reacquire), _ptr(st), n, _ptr(out),
+                                                     _ptr(tracks.workspace), int(tracks.boxes_valid), self._stream()))
         tracks.boxes_valid = True
         self._keep_tracks = (tracks, track_of_car)
         return out.view(self.B, self.A, 2) if state is None else out

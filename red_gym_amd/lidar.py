@@ -84,8 +84,9 @@ class LidarBitmap:
             out = torch.empty(shape, dtype=torch.uint8, device=self.device)
         assert out.is_contiguous() and out.dtype == torch.uint8 and tuple(out.shape) == shape
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        _lib.check(self.lib.f110_bitmap_render(self.h, s.data_ptr(), int(s.dtype == torch.float64), n,
-                                               s.stride(0) if n > 1 else self.num_beams, out.data_ptr(), stream))
+        with torch.cuda.device(self.device):  # the library launches on the current device's stream (f110_hip.h, conventions)
+            _lib.check(self.lib.f110_bitmap_render(self.h, s.data_ptr(), int(s.dtype == torch.float64), n,
+                                                   s.stride(0) if n > 1 else self.num_beams, out.data_ptr(), stream))
         out = out.reshape(scans.shape[:-1] + shape[1:]) if not single else out[0]
         return out
 
@@ -99,8 +100,9 @@ class LidarBitmap:
         n = s.shape[0]
         out = torch.empty((n, self.target_beam_count, 2), dtype=torch.int32, device=self.device)
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        _lib.check(self.lib.f110_bitmap_points(self.h, s.data_ptr(), int(s.dtype == torch.float64), n, s.stride(0),
-                                               out.data_ptr(), stream))
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.f110_bitmap_points(self.h, s.data_ptr(), int(s.dtype == torch.float64), n, s.stride(0),
+                                                   out.data_ptr(), stream))
         torch.cuda.current_stream(self.device).synchronize()  # `s` may be a temporary
         return out
 
@@ -159,8 +161,9 @@ def scan_occupancy(scans, max_range=30.0, lo=-10.0, hi=10.0, grid_size=256):
     cs, sn = (torch.as_tensor(t, device=s.device) for t in occupancy_tables(nb))
     out = torch.empty((n, grid_size, grid_size), dtype=torch.uint8, device=s.device)
     stream = torch.cuda.current_stream(s.device).cuda_stream
-    _lib.check(lib.f110_scan_occupancy(s.data_ptr(), int(s.dtype == torch.float64), n, s.stride(0) if n > 1 else nb, nb,
-                                       cs.data_ptr(), sn.data_ptr(), max_range, lo, hi, grid_size, out.data_ptr(),
-                                       stream))
+    with torch.cuda.device(s.device):
+        _lib.check(lib.f110_scan_occupancy(s.data_ptr(), int(s.dtype == torch.float64), n, s.stride(0) if n > 1 else nb, nb,
+                                           cs.data_ptr(), sn.data_ptr(), max_range, lo, hi, grid_size, out.data_ptr(),
+                                           stream))
     torch.cuda.current_stream(s.device).synchronize()  # cs / sn are temporaries
     return out[0] if single else out

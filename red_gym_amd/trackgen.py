@@ -162,8 +162,9 @@ def generate(seed, device='cuda', width_units=WIDTH, stroke_pixels=STROKE_PIXELS
     pts = torch.as_tensor(np.ascontiguousarray(cl), device=dev)
     free = torch.empty((MAP_PIXELS, MAP_PIXELS), dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
-    _lib.check(lib.f110_track_mask(pts.data_ptr(), len(cl), 1, MAP_PIXELS, MAP_PIXELS, x0, y0, UNITS_PER_PIXEL,
-                                   float(width_units), 0.5 * stroke_pixels * UNITS_PER_PIXEL, free.data_ptr(), stream))
+    with torch.cuda.device(free.device):  # stateless entry point: launches on the current device's stream
+        _lib.check(lib.f110_track_mask(pts.data_ptr(), len(cl), 1, MAP_PIXELS, MAP_PIXELS, x0, y0, UNITS_PER_PIXEL,
+                                       float(width_units), 0.5 * stroke_pixels * UNITS_PER_PIXEL, free.data_ptr(), stream))
     t = Track()
     t.free = free
     t.resolution = RESOLUTION

@@ -197,7 +197,8 @@ class F110VecEnv(object):
         self.eng._grow_noise_if_needed()
         if self.eng.launch_epoch() != self._lg_epoch:
             self.build_step_graph(self._lg_how)
-        _lib.check(self.eng.lib.f110_graph_launch(self._lg, self.eng._stream()))
+        with torch.cuda.device(self.device):
+            _lib.check(self.eng.lib.f110_graph_launch(self._lg, self.eng._stream()))
         self.eng.host_steps_bound += 1
         return self._result()
 

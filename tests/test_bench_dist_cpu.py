@@ -23,7 +23,8 @@ def _worker(rank, world, port, q):
         steps.append(k)
         time.sleep(0.01 * (1 + ranks.rank))
     elapsed = bench.timed_steps(ranks, step, 5)
-    q.put((rank, elapsed, len(steps), float(poses.sum()), float(acts.sum())))
+    names = ranks.gather_names('dev-of-rank-%d' % rank)
+    q.put((rank, elapsed, len(steps), float(poses.sum()), float(acts.sum()), list(ranks.last_per_rank), names))
     ranks.close()
 
 
@@ -38,7 +39,9 @@ def test_two_rank_sharding_and_timing():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, e0, n0, ps0, as0), (r1, e1, n1, ps1, as1) = res
+    (r0, e0, n0, ps0, as0, pr0, nm0), (r1, e1, n1, ps1, as1, pr1, nm1) = res
+    assert pr0 == pr1 and len(pr0) == 2 and max(pr0) <= e0 and pr0[1] > pr0[0] * 1.5   # every rank's own time: the straggler shows
+    assert nm0 == nm1 == ['dev-of-rank-0', 'dev-of-rank-1']
     assert (r0, r1) == (0, 1) and n0 == n1 == 5          # EXACTLY K steps on every rank
     assert e0 == e1                                      # MAX over ranks is what both report
     assert e0 >= 5 * 0.02 * 0.9                          # the slow rank (20 ms/step) sets it
@@ -54,7 +57,21 @@ def test_single_rank_needs_no_process_group():
     assert ranks.world == 1 and ranks.max_over_ranks(1.5) == 1.5
     n = []
     assert bench.timed_steps(ranks, lambda k: n.append(k), 7) >= 0 and n == list(range(7))
+    assert ranks.last_per_rank is not None and len(ranks.last_per_rank) == 1 and ranks.gather_names('x') == ['x']
     ranks.close()
+
+
+def test_forced_one_rank_group_runs_the_collectives():
+    """force_group=True builds a process group for ONE rank (what tests/test_gpu_rccl.py does with RCCL on the GPU box):
+    barrier, all_gather, all_reduce(MAX) and destroy_process_group execute."""
+    import subprocess
+    code = ('import sys; sys.path.insert(0, %r); import bench; r = bench.Ranks("gloo", None, force_group=True); '
+            'assert r.grouped and r.dist.is_initialized() and r.dist.get_world_size() == 1; '
+            'e = bench.timed_steps(r, lambda k: None, 3); assert len(r.last_per_rank) == 1 and r.last_per_rank[0] <= e; '
+            'assert r.gather_names("abc") == ["abc"]; r.close(); assert not r.dist.is_initialized(); print("ok")' % ROOT)
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT')}
+    p = subprocess.run([sys.executable, '-c', code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120, text=True)
+    assert p.returncode == 0 and p.stdout.strip().endswith('ok'), p.stderr
 
 
 def _run_bench(args, extra_env, timeout=180):
@@ -80,6 +97,8 @@ def test_self_launch_starts_its_own_ranks():
     out = lines[0]
     assert out['n_gpus'] == 2 and out['steps'] == 6 and out['warmup'] == 2 and out['data'] == 'stub'
     assert out['ms_per_step'] >= 20 * 0.9                       # rank 1 sleeps 20 ms per step
+    assert len(out['per_rank_ms']) == 2 and out['per_rank_ms'][1] > 1.5 * out['per_rank_ms'][0]
+    assert max(out['per_rank_ms']) <= out['ms_per_step'] and out['devices'] == ['stub-cpu-0', 'stub-cpu-1']
     assert abs(out['value'] - 2 * 32 * 6 / (out['ms_per_step'] * 6e-3)) < 1e-6 * out['value']
 
 
