@@ -50,6 +50,8 @@ extern "C" {
 
 #define F110_MAX_AGENTS 32
 #define F110_MAX_MAPS 64  /* map slots of one handle (f110_set_map_slot_*, f110_assign_maps) */
+#define F110_MAX_NOISE_SLOTS 64 /* noise slots (= distinct seeds) of one handle (f110_set_noise_generator, f110_assign_noise) */
+#define F110_NOISE_INITIAL_ROWS 1024 /* rows per slot of a generated noise table when it is first allocated (it doubles on demand) */
 #define F110_NUM_PARAMS 18
 #define F110_RK4 1   /* Integrator.RK4   base_classes.py:40-42 */
 #define F110_EULER 2 /* Integrator.Euler */
@@ -116,6 +118,22 @@ const char *f110_last_error(void);
  * the beam tables fixed at construction (:116-156). */
 int f110_update_params(f110_handle *h, const double *params18_host, int32_t agent_idx);
 
+/* Per-env constructor arguments.  One handle stands in for num_envs F110Env instances; the reference constructs each
+ * with its own `params` (f110_env.py:125-128) and `seed` (:102-105).  Like maps (slots + f110_assign_maps), both exist
+ * as SLOTS plus an env -> slot table:
+ *   params slot = the `params` dict of one reference env: Simulator.params (the GJK quads, base_classes.py:542) and the
+ *     RaceCar.params of every agent (:84,169).  f110_set_params_slots replaces the whole slot table ([n_slots,18] host,
+ *     1 <= n_slots <= num_envs: "every env its own vehicle" is n_slots = num_envs with the identity assignment);
+ *     f110_set_params_slot changes one slot -- agent_idx < 0: as at construction (Simulator copy + every agent), else only
+ *     RaceCar.params of that agent (Simulator.update_params on that env, :507-527); a slot beyond the current count extends
+ *     the table with copies of slot 0.  f110_update_params (above) keeps applying to every slot.  f110_assign_params: host
+ *     int32 [num_envs], NULL = all envs on slot 0.  The beam tables (scan angles, cosines, side distances) stay per handle:
+ *     in the reference they are class-level statics fixed by the FIRST RaceCar a process constructs (base_classes.py:116-156).
+ *   noise slot = one seed: see f110_set_noise_generator / f110_set_noise_slot / f110_assign_noise below. */
+int f110_set_params_slots(f110_handle *h, const double *params_host, int32_t n_slots);
+int f110_set_params_slot(f110_handle *h, int32_t slot, const double *params18_host, int32_t agent_idx);
+int f110_assign_params(f110_handle *h, const int32_t *slot_of_env_host);
+
 /* Optional: replace the library's libm-computed tables by the caller's
  * (numpy-computed, as in the reference).  sines/cosines: [theta_dis]
  * (laser_models.py:379-381); scan_angles/beam_cosines/side_distances:
@@ -169,11 +187,50 @@ int f110_edt_squared(const uint8_t *free_mask_host, int32_t height, int32_t widt
  * row pass with the row's g^2 in LDS, exact like the host version.  height, width <= 32768. */
 int f110_edt_squared_dev(const uint8_t *free_mask_dev, int32_t height, int32_t width, uint32_t *d2_out_dev, void *stream);
 
-/* Lidar noise: table[k] = k-th `rng.normal(0, std, num_beams)` draw of
- * default_rng(seed) (laser_models.py:450-452, base_classes.py:202), [T,num_beams]
- * fp64 on the host.  T = 0 / NULL switches noise off.  A car whose noise_step
- * reaches T reads row noise_step % T (the host grows the table before that). */
+/* Lidar noise.  Reference: every scan adds `rng.normal(0, std, num_beams)` drawn from the car's own
+ * np.random.default_rng(seed), re-created at every reset (laser_models.py:450-452, base_classes.py:117,202); all cars of an
+ * env share the seed, so a car's noise row is a function of (seed, scans since its reset).  The handle keeps the rows of
+ * each seed ONCE, in a noise slot, indexed by every car's own counter (f110_buffers.noise_step); f110_assign_noise gives
+ * every env its slot (host int32 [num_envs], NULL = all on slot 0).  A slot is filled either way:
+ *   f110_set_noise_generator -- the rows are PRODUCED ON THE DEVICE by a bit-level restatement of NumPy's PCG64 +
+ *     ziggurat `normal` (csrc/f110_noise.h).  pcg64_state_inc = {state_lo, state_hi, inc_lo, inc_hi} of
+ *     np.random.PCG64(seed).state['state'] (NumPy's SeedSequence hashing stays with NumPy; a C caller may pass any
+ *     128-bit state and odd increment).  Setting a generator restarts every generated slot at row 0.
+ *   f110_set_noise_slot -- rows [T,num_beams] fp64 from the host (any table; tests, non-NumPy streams).
+ *     f110_set_noise_table(h, tbl, T) is slot 0; T = 0 / NULL switches noise off for the whole handle.
+ * Rows: f110_noise_ensure(h, rows, stream) makes rows 0 .. rows-1 (above the floor) readable for work enqueued on
+ * `stream` afterwards -- call it before a step with rows > the largest noise_step any car can have in that step;
+ * generated slots produce what is missing (a one-wavefront kernel per slot; the table doubles when it must: cold path,
+ * synchronises), host tables that are too short give F110_E_INVALID.  f110_noise_prefetch(h, rows) starts producing
+ * ahead of time on the handle's own stream, beside the caller's work; a later f110_noise_ensure only waits for it.
+ * Floor: when no car can read rows below `lo` any more (autoreset off and every car past them), f110_noise_set_floor
+ * lets the table recycle them -- it is a ring, so a run of any length holds a window of rows in constant memory.
+ * Lowering the floor again (a reset) re-produces the dropped rows from the seeds.  A car whose row lies outside
+ * [floor, rows produced) sets F110_DEVERR_NOISE_WINDOW in the device error word instead of reading silently.
+ * The table's address reaches the kernels through a device-resident descriptor: growth never invalidates a captured
+ * hipGraph (the launch epoch does not move). */
 int f110_set_noise_table(f110_handle *h, const double *table_host, int64_t T);
+int f110_set_noise_slot(f110_handle *h, int32_t slot, const double *table_host, int64_t T);
+int f110_set_noise_generator(f110_handle *h, int32_t slot, const uint64_t *pcg64_state_inc, double std_dev);
+int f110_assign_noise(f110_handle *h, const int32_t *slot_of_env_host);
+int f110_noise_ensure(f110_handle *h, int64_t rows, void *stream);
+int f110_noise_prefetch(f110_handle *h, int64_t rows);
+int f110_noise_set_floor(f110_handle *h, int64_t lo, void *stream);
+/* floor, rows readable by the kernels (a prefetch still in flight not counted), rows per slot of the ring, slots, bytes held
+ * (host-side bookkeeping, no synchronisation; any pointer may be NULL) */
+int f110_noise_info(f110_handle *h, int64_t *lo, int64_t *hi, int64_t *cap, int32_t *slots, int64_t *bytes);
+/* Tests / diagnostics: the noise values of rows row0 .. row0+n_rows-1 of a slot, [n_rows,num_beams] fp64 to the host
+ * (synchronises; F110_E_INDEX when a row is not in the table). */
+int f110_noise_read(f110_handle *h, int32_t slot, int64_t row0, int64_t n_rows, double *out_host);
+
+/* Device error word: conditions a kernel can only detect while it runs are OR-ed into one word per handle instead of
+ * being silent.  Synchronises the device, returns the word and clears it.  F110_DEVERR_NOISE_WINDOW: a car's noise row
+ * was not in the table (f110_noise_ensure not called, or the floor above a live car).  F110_DEVERR_BOUNDS: only in the
+ * bounds-checked debug build of the library (-DF110_BOUNDS, tools/build_variant.sh): an index into a device table was out
+ * of range; bits 8.. name the table (csrc/f110_kernels.h BOUNDS_*). */
+#define F110_DEVERR_NOISE_WINDOW 0x1u
+#define F110_DEVERR_BOUNDS 0x2u
+int f110_device_errors(f110_handle *h, uint32_t *flags_out);
 
 int f110_bind(f110_handle *h, const f110_buffers *bufs);
 

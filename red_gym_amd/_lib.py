@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('F110_LIB') or os.path.join(_HERE, 'libf110_hip.so')  # F110_LIB: kernel-variant sweeps
 
 F110_MAX_AGENTS = 32
+F110_MAX_NOISE_SLOTS = 64
 F110_NUM_PARAMS = 18
 F110_RK4, F110_EULER = 1, 2
 E_INVALID, E_HIP, E_NOMAP, E_INDEX, E_UNBOUND = -1, -2, -3, -4, -5
@@ -61,7 +62,19 @@ SYMBOLS = {
     'f110_get_map_dt': [_VP, _VP],
     'f110_edt_squared': [_VP, _I32, _I32, _VP],
     'f110_edt_squared_dev': [_VP, _I32, _I32, _VP, _VP],
+    'f110_set_params_slots': [_VP, _VP, _I32],
+    'f110_set_params_slot': [_VP, _I32, _VP, _I32],
+    'f110_assign_params': [_VP, _VP],
     'f110_set_noise_table': [_VP, _VP, _I64],
+    'f110_set_noise_slot': [_VP, _I32, _VP, _I64],
+    'f110_set_noise_generator': [_VP, _I32, _VP, _D],
+    'f110_assign_noise': [_VP, _VP],
+    'f110_noise_ensure': [_VP, _I64, _VP],
+    'f110_noise_prefetch': [_VP, _I64],
+    'f110_noise_set_floor': [_VP, _I64, _VP],
+    'f110_noise_info': [_VP, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int64)],
+    'f110_noise_read': [_VP, _I32, _I64, _I64, _VP],
+    'f110_device_errors': [_VP, C.POINTER(C.c_uint32)],
     'f110_bind': [_VP, C.POINTER(Buffers)],
     'f110_reset': [_VP, _VP, _VP, _VP],
     'f110_step': [_VP, _VP, _VP],

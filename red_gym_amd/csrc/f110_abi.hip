@@ -67,9 +67,14 @@ struct DeviceScope {
 
 struct f110_handle {
     f110_config cfg;
-    Params params;                    // Simulator.params: the constructor's (GJK vertices, base_classes.py:542)
-    Params agent_params[F110_MAX_AGENTS]; // RaceCar.params per agent index
-    Params *d_agent_params = nullptr;
+    // Vehicle parameters, [slots][1 + A]: per params slot (the `params` one reference env was constructed with) entry 0 =
+    // Simulator.params (GJK vertices, base_classes.py:542), entry 1 + i = RaceCar.params of agent i
+    std::vector<Params> h_params;
+    int param_slots = 1;
+    Params *d_params = nullptr;
+    int d_params_slots = 0;           // slots the device allocation holds
+    int32_t *d_env_params = nullptr;  // dev [B] params slot of every env; passed to the kernels only when `multi_params`
+    bool multi_params = false;
     OppPair *d_opp_pairs = nullptr;   // [N, A-1] opponent ray-cast scratch
     bool has_map = false, bound = false;
     // Bumped whenever a later f110_step would enqueue different kernels or by-value arguments than an earlier one
@@ -84,9 +89,30 @@ struct f110_handle {
     int cs_len = 0;
     double2 *d_beam_cs = nullptr;     // {cos, sin}(scan_angles) for the opponent ray cast
     std::vector<double> h_sines, h_cosines;
-    double2 *d_noise_side = nullptr;  // [max(T,1), nb] {noise, side distance}
-    long long noise_T = 0;
-    std::vector<double> h_noise, h_side; // host copies the interleaved table is rebuilt from
+    // Lidar noise (f110_noise.h): [noise_slots][cap][nb] {noise, side distance} pairs, rows lo .. hi-1 present; the kernels
+    // find it through d_noise_desc, whose address never changes
+    double2 *d_noise = nullptr;
+    long long noise_cap = 0, noise_lo = 0, noise_hi = 0; // cap: rows per slot (a power of two); noise off: cap 1, hi = "infinity"
+    int noise_slots = 1;
+    bool noise_on = false;
+    NoiseDesc *d_noise_desc = nullptr;
+    struct NoiseSlot {
+        int kind = 0;                 // 0 unset (zeros), 1 host-fed table, 2 generator
+        std::vector<double> rows;     // host-fed: [T, nb]
+        long long T = 0;              // rows the slot can serve: host-fed = table length, generator = rows produced
+        NoiseGen seed;                // generator: the stream at row 0
+    };
+    NoiseSlot nslots[F110_MAX_NOISE_SLOTS];
+    NoiseGen *d_noise_gen = nullptr;  // [F110_MAX_NOISE_SLOTS] device generator states
+    int32_t *d_env_noise = nullptr;   // dev [B] noise slot of every env; passed only when `multi_noise`
+    bool multi_noise = false;
+    hipStream_t noise_stream = nullptr; // the generator runs here, beside the caller's stream (f110_noise_prefetch)
+    hipEvent_t noise_ev = nullptr;
+    long long noise_pending_hi = 0;   // rows a prefetch in flight on noise_stream will have produced (0: none in flight)
+    struct Retired { void *ptr; hipEvent_t ev; };
+    std::vector<Retired> retired;     // old noise tables, freed once the work that may read them has drained
+    uint32_t *d_err = nullptr;        // device error word (f110_device_errors)
+    std::vector<double> h_side;       // side distances (interleaved into the noise pairs)
     // Maps.  Slot 0 is "the" map of the reference's API; further slots let blocks of envs of one shard run on
     // different maps (one handle standing in for many F110Env instances with their own map each).
     struct MapSlot {
@@ -110,6 +136,23 @@ struct f110_handle {
 };
 
 extern "C" const char *f110_last_error(void) { return g_err; }
+
+// Launches go to the caller's stream, which belongs to the calling thread's CURRENT device: it must be the handle's.
+// (Checked, not switched: hipGetDevice is a thread-local read; switching would cost two runtime calls per step and
+// still leave the caller's stream on the wrong device.)
+static int check_current_device(int dev, const char *who)
+{
+    int cur = -1;
+    HIP_TRY(hipGetDevice(&cur));
+    if (cur != dev)
+        return fail(F110_E_INVALID, "%s: the handle lives on device %d but the calling thread's current device is %d; make the "
+                    "handle's device current (hipSetDevice / torch.cuda.device) and pass a stream of that device", who, dev, cur);
+    return F110_OK;
+}
+
+
+
+static int check_device(const f110_handle *h, const char *who) { return check_current_device(h->cfg.device, who); }
 
 // ---------------------------------------------------------------- exact squared EDT (host)
 // Meijster, Roerdink, Hesselink (2000): two passes, integer arithmetic only, so
@@ -253,8 +296,9 @@ static int upload_beam_cs(f110_handle *h, const double *scan_angles)
     return F110_OK;
 }
 
-static int upload_agent_params(f110_handle *h);
-static int rebuild_noise_side(f110_handle *h);
+static int upload_params(f110_handle *h);
+static int noise_init(f110_handle *h);
+static int noise_side_changed(f110_handle *h);
 
 // scratch of the opponent ray cast: allocated here, never in f110_step
 static int alloc_opp_pairs(f110_handle *h)
@@ -302,8 +346,11 @@ extern "C" int f110_create(const f110_config *cfg, f110_handle **out)
     f110_handle *h = new (std::nothrow) f110_handle();
     if (!h) return fail(F110_E_INVALID, "f110_create: out of host memory");
     h->cfg = *cfg;
-    memcpy(h->params.v, cfg->params, sizeof(double) * P_COUNT);
-    for (int i = 0; i < F110_MAX_AGENTS; i++) h->agent_params[i] = h->params;
+    {
+        Params p0;
+        memcpy(p0.v, cfg->params, sizeof(double) * P_COUNT);
+        h->h_params.assign((size_t)cfg->num_agents + 1, p0); // slot 0: Simulator.params + every agent's RaceCar.params
+    }
     memset(&h->bufs, 0, sizeof(h->bufs));
     for (auto &sl : h->slots) memset(&sl.dev, 0, sizeof(sl.dev));
     // laser_models.py:367-368
@@ -315,10 +362,10 @@ extern "C" int f110_create(const f110_config *cfg, f110_handle **out)
     h->h_sines = s;
     h->h_cosines = c;
     h->h_side = side;
-    if ((rc = upload_cs(h)) || (rc = rebuild_noise_side(h)) ||
+    if ((rc = upload_cs(h)) ||
         (rc = upload(&h->d_scan_angles, ang.data(), ang.size())) || (rc = upload_beam_cs(h, ang.data())) ||
         (rc = upload(&h->d_beam_cosines, bcos.data(), bcos.size())) ||
-        (rc = upload(&h->d_side, side.data(), side.size())) || (rc = set_beam_order(h)) || (rc = upload_agent_params(h)) || (rc = alloc_opp_pairs(h))) {
+        (rc = upload(&h->d_side, side.data(), side.size())) || (rc = noise_init(h)) || (rc = set_beam_order(h)) || (rc = upload_params(h)) || (rc = alloc_opp_pairs(h))) {
         f110_destroy(h);
         return rc;
     }
@@ -330,10 +377,14 @@ extern "C" void f110_destroy(f110_handle *h)
 {
     if (!h) return;
     DeviceScope on_dev(h->cfg.device);
-    void *ptrs[] = {h->d_cs, h->d_beam_cs, h->d_noise_side, h->d_scan_angles, h->d_beam_cosines, h->d_side,
-                    h->d_chunk0, h->d_agent_params, h->d_opp_pairs, h->d_maps, h->d_env_map};
+    (void)hipDeviceSynchronize();
+    void *ptrs[] = {h->d_cs, h->d_beam_cs, h->d_noise, h->d_noise_desc, h->d_noise_gen, h->d_env_noise, h->d_scan_angles, h->d_beam_cosines,
+                    h->d_side, h->d_chunk0, h->d_params, h->d_env_params, h->d_opp_pairs, h->d_maps, h->d_env_map, h->d_err};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    for (auto &r : h->retired) { (void)hipFree(r.ptr); (void)hipEventDestroy(r.ev); }
+    if (h->noise_ev) (void)hipEventDestroy(h->noise_ev);
+    if (h->noise_stream) (void)hipStreamDestroy(h->noise_stream);
     for (auto &sl : h->slots)
         for (void *p : {(void *)sl.d_cells, (void *)sl.d_cells_far, (void *)sl.d_lut, (void *)sl.d_lut_lds, (void *)sl.d_dt})
             if (p) (void)hipFree(p);
@@ -341,12 +392,18 @@ extern "C" void f110_destroy(f110_handle *h)
     delete h;
 }
 
-static int upload_agent_params(f110_handle *h)
+static int upload_params(f110_handle *h)
 {
-    if (!h->d_agent_params) HIP_TRY(hipMalloc((void **)&h->d_agent_params, sizeof(Params) * F110_MAX_AGENTS));
+    const int A1 = h->cfg.num_agents + 1;
     // enqueued steps may still read the table
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(h->d_agent_params, h->agent_params, sizeof(Params) * F110_MAX_AGENTS, hipMemcpyHostToDevice));
+    if (h->d_params_slots < h->param_slots) {
+        if (h->d_params) { (void)hipFree(h->d_params); h->d_params = nullptr; }
+        HIP_TRY(hipMalloc((void **)&h->d_params, sizeof(Params) * (size_t)h->param_slots * A1));
+        h->d_params_slots = h->param_slots;
+        h->epoch++; // the kernels take the pointer by value
+    }
+    HIP_TRY(hipMemcpy(h->d_params, h->h_params.data(), sizeof(Params) * (size_t)h->param_slots * A1, hipMemcpyHostToDevice));
     return F110_OK;
 }
 
@@ -355,9 +412,79 @@ extern "C" int f110_update_params(f110_handle *h, const double *p, int32_t agent
     if (!h || !p) return fail(F110_E_INVALID, "f110_update_params: null argument");
     if (agent_idx >= h->cfg.num_agents) return fail(F110_E_INDEX, "Index given is out of bounds for list of agents.");
     ON_DEVICE(h->cfg.device);
-    for (int i = 0; i < h->cfg.num_agents; i++)
-        if (agent_idx < 0 || agent_idx == i) memcpy(h->agent_params[i].v, p, sizeof(double) * P_COUNT);
-    return upload_agent_params(h);
+    const int A1 = h->cfg.num_agents + 1;
+    for (int sl = 0; sl < h->param_slots; sl++)
+        for (int i = 0; i < h->cfg.num_agents; i++)
+            if (agent_idx < 0 || agent_idx == i) memcpy(h->h_params[(size_t)sl * A1 + 1 + i].v, p, sizeof(double) * P_COUNT);
+    return upload_params(h);
+}
+
+// ---- per-env constructor arguments: params slots
+static int check_params18(const double *p, const char *who)
+{
+    for (int i = 0; i < P_COUNT; i++)
+        if (!std::isfinite(p[i])) return fail(F110_E_INVALID, "%s: parameter %d is not finite", who, i);
+    return F110_OK;
+}
+
+extern "C" int f110_set_params_slots(f110_handle *h, const double *params, int32_t n_slots)
+{
+    if (!h || !params) return fail(F110_E_INVALID, "f110_set_params_slots: null argument");
+    if (n_slots < 1 || n_slots > h->cfg.num_envs) return fail(F110_E_INDEX, "f110_set_params_slots: %d slots (1..num_envs = %d)", n_slots, h->cfg.num_envs);
+    for (int sl = 0; sl < n_slots; sl++)
+        if (int rc = check_params18(params + (size_t)sl * P_COUNT, "f110_set_params_slots")) return rc;
+    ON_DEVICE(h->cfg.device);
+    const int A1 = h->cfg.num_agents + 1;
+    h->h_params.resize((size_t)n_slots * A1);
+    for (int sl = 0; sl < n_slots; sl++)
+        for (int i = 0; i < A1; i++) memcpy(h->h_params[(size_t)sl * A1 + i].v, params + (size_t)sl * P_COUNT, sizeof(double) * P_COUNT);
+    const bool shrunk = n_slots < h->param_slots;
+    h->param_slots = n_slots;
+    if (shrunk && h->multi_params) { h->multi_params = false; h->epoch++; } // the assignment may name slots that are gone: all envs back on slot 0
+    return upload_params(h);
+}
+
+extern "C" int f110_set_params_slot(f110_handle *h, int32_t slot, const double *p, int32_t agent_idx)
+{
+    if (!h || !p) return fail(F110_E_INVALID, "f110_set_params_slot: null argument");
+    if (slot < 0 || slot >= h->cfg.num_envs) return fail(F110_E_INDEX, "f110_set_params_slot: slot %d outside 0..%d", slot, h->cfg.num_envs - 1);
+    if (agent_idx >= h->cfg.num_agents) return fail(F110_E_INDEX, "Index given is out of bounds for list of agents.");
+    if (int rc = check_params18(p, "f110_set_params_slot")) return rc;
+    ON_DEVICE(h->cfg.device);
+    const int A1 = h->cfg.num_agents + 1;
+    if (slot >= h->param_slots) { // new slots start as copies of slot 0
+        h->h_params.resize((size_t)(slot + 1) * A1);
+        for (int sl = h->param_slots; sl <= slot; sl++)
+            for (int i = 0; i < A1; i++) h->h_params[(size_t)sl * A1 + i] = h->h_params[i];
+        h->param_slots = slot + 1;
+    }
+    for (int i = 0; i < A1; i++) {
+        const bool sim = i == 0;
+        if (agent_idx < 0 || (!sim && agent_idx == i - 1)) memcpy(h->h_params[(size_t)slot * A1 + i].v, p, sizeof(double) * P_COUNT);
+    }
+    return upload_params(h);
+}
+
+extern "C" int f110_assign_params(f110_handle *h, const int32_t *slot_of_env)
+{
+    if (!h) return fail(F110_E_INVALID, "f110_assign_params: null handle");
+    const int B = h->cfg.num_envs;
+    std::vector<int32_t> m(B, 0);
+    bool multi = false;
+    if (slot_of_env)
+        for (int e = 0; e < B; e++) {
+            if (slot_of_env[e] < 0 || slot_of_env[e] >= h->param_slots)
+                return fail(F110_E_INDEX, "f110_assign_params: env %d uses params slot %d, the handle has %d", e, slot_of_env[e], h->param_slots);
+            m[e] = slot_of_env[e];
+            multi = multi || m[e] != 0;
+        }
+    ON_DEVICE(h->cfg.device);
+    HIP_TRY(hipDeviceSynchronize());
+    if (!h->d_env_params) HIP_TRY(hipMalloc((void **)&h->d_env_params, sizeof(int32_t) * B));
+    HIP_TRY(hipMemcpy(h->d_env_params, m.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice));
+    h->multi_params = multi;
+    h->epoch++;
+    return F110_OK;
 }
 
 extern "C" int f110_set_tables(f110_handle *h, const double *sines, const double *cosines, const double *ang,
@@ -376,7 +503,7 @@ extern "C" int f110_set_tables(f110_handle *h, const double *sines, const double
     if (side) {
         if ((rc = upload(&h->d_side, side, h->cfg.num_beams))) return rc;
         h->h_side.assign(side, side + h->cfg.num_beams);
-        if ((rc = rebuild_noise_side(h))) return rc;
+        if ((rc = noise_side_changed(h))) return rc;
     }
     return rc;
 }
@@ -712,36 +839,376 @@ extern "C" int f110_assign_maps(f110_handle *h, const int32_t *map_of_env)
     return F110_OK;
 }
 
+// ---------------------------------------------------------------- lidar noise (f110_noise.h)
+__global__ void noise_publish_kernel(NoiseDesc *dst, NoiseDesc d) { *dst = d; }
+
+static long long pow2_at_least(long long n)
+{
+    long long c = 1;
+    while (c < n) c <<= 1;
+    return c;
+}
+
+static void noise_reap(f110_handle *h, bool all)
+{
+    for (size_t i = 0; i < h->retired.size();) {
+        if (all || hipEventQuery(h->retired[i].ev) == hipSuccess) {
+            (void)hipFree(h->retired[i].ptr);
+            (void)hipEventDestroy(h->retired[i].ev);
+            h->retired.erase(h->retired.begin() + i);
+        } else i++;
+    }
+}
+
+// rows every active slot can serve
+static void noise_recompute_hi(f110_handle *h)
+{
+    long long hi = -1;
+    for (int sl = 0; sl < h->noise_slots; sl++) {
+        const auto &ns = h->nslots[sl];
+        if (ns.kind == 0) continue;
+        hi = hi < 0 ? ns.T : std::min(hi, ns.T);
+    }
+    h->noise_on = hi >= 0;
+    h->noise_hi = hi < 0 ? 0 : hi;
+}
+
+// the descriptor the kernels read, written in stream order
+static int noise_publish(f110_handle *h, hipStream_t st)
+{
+    NoiseDesc d;
+    d.base = h->d_noise; d.cap = h->noise_cap; d.mask = h->noise_cap - 1;
+    d.lo = h->noise_on ? h->noise_lo : 0;
+    d.hi = h->noise_on ? h->noise_hi : 0x7fffffffffffffffll; // noise off: every row is the row of zeros
+    hipLaunchKernelGGL(noise_publish_kernel, dim3(1), dim3(1), 0, st, h->d_noise_desc, d);
+    HIP_TRY(hipGetLastError());
+    return F110_OK;
+}
+
+// (Re)allocates the table for `slots` slots of `cap` rows, every pair {0, side}; rows lo .. hi-1 of the old table move
+// over.  Cold path: synchronises the device, so nothing reads the old table any more and the new one is complete on return.
+static int noise_resize(f110_handle *h, int slots, long long cap)
+{
+    const int nb = h->cfg.num_beams;
+    HIP_TRY(hipDeviceSynchronize());
+    noise_reap(h, true);
+    double2 *nt = nullptr;
+    const size_t total = (size_t)slots * (size_t)cap;
+    HIP_TRY(hipMalloc((void **)&nt, total * nb * sizeof(double2)));
+    {
+        const long long items = (long long)total * nb;
+        hipLaunchKernelGGL(noise_interleave_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, nullptr, (const double *)nullptr,
+                           (long long)total, nb, h->d_side, nt, 0, (long long)total, (long long)0x7fffffffffffffffll);
+    }
+    if (h->d_noise && h->noise_on && h->noise_hi > h->noise_lo) {
+        const int ms = std::min(slots, h->noise_slots);
+        const long long items = (h->noise_hi - h->noise_lo) * nb * ms;
+        hipLaunchKernelGGL(noise_move_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, nullptr, h->d_noise, h->noise_cap,
+                           h->noise_cap - 1, nt, cap, cap - 1, ms, h->noise_lo, h->noise_hi, nb);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    if (h->d_noise) (void)hipFree(h->d_noise);
+    h->d_noise = nt;
+    h->noise_cap = cap;
+    h->noise_slots = slots;
+    return noise_publish(h, nullptr);
+}
+
+static int noise_init(f110_handle *h)
+{
+    HIP_TRY(hipMalloc((void **)&h->d_noise_desc, sizeof(NoiseDesc)));
+    HIP_TRY(hipMalloc((void **)&h->d_noise_gen, sizeof(NoiseGen) * F110_MAX_NOISE_SLOTS));
+    HIP_TRY(hipMemset(h->d_noise_gen, 0, sizeof(NoiseGen) * F110_MAX_NOISE_SLOTS));
+    HIP_TRY(hipMalloc((void **)&h->d_err, sizeof(uint32_t)));
+    HIP_TRY(hipMemset(h->d_err, 0, sizeof(uint32_t)));
+    HIP_TRY(hipStreamCreateWithFlags(&h->noise_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&h->noise_ev, hipEventDisableTiming));
+    return noise_resize(h, 1, 1); // noise off: one row of zeros
+}
+
+static int noise_side_changed(f110_handle *h)
+{
+    const long long items = (long long)h->noise_slots * h->noise_cap * h->cfg.num_beams;
+    HIP_TRY(hipDeviceSynchronize());
+    hipLaunchKernelGGL(noise_set_side_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, nullptr, h->d_noise,
+                       (long long)h->noise_slots * h->noise_cap, h->cfg.num_beams, h->d_side);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    return F110_OK;
+}
+
+// a prefetch in flight on the generator's stream becomes part of the table for work enqueued on `st` from now on
+static int noise_absorb_pending(f110_handle *h, hipStream_t st)
+{
+    if (!h->noise_pending_hi) return F110_OK;
+    HIP_TRY(hipStreamWaitEvent(st, h->noise_ev, 0));
+    for (int sl = 0; sl < h->noise_slots; sl++)
+        if (h->nslots[sl].kind == 2) h->nslots[sl].T = std::max(h->nslots[sl].T, h->noise_pending_hi);
+    h->noise_pending_hi = 0;
+    noise_recompute_hi(h);
+    return noise_publish(h, st);
+}
+
+static bool noise_has_generators(const f110_handle *h)
+{
+    for (int sl = 0; sl < h->noise_slots; sl++)
+        if (h->nslots[sl].kind == 2) return true;
+    return false;
+}
+
+static int noise_launch_generator(f110_handle *h, long long r1, hipStream_t st)
+{
+    NoiseGenArgs g;
+    g.gen = h->d_noise_gen; g.base = h->d_noise; g.mask = h->noise_cap - 1; g.cap = h->noise_cap; g.lo = h->noise_lo; g.r1 = r1;
+    g.nb = h->cfg.num_beams; g.side = h->d_side;
+    hipLaunchKernelGGL(noise_rows_kernel, dim3(h->noise_slots), dim3(64), 0, st, g);
+    HIP_TRY(hipGetLastError());
+    return F110_OK;
+}
+
+// every generator slot restarts at row 0 (its seed state); rows below the floor will be skipped, not stored
+static int noise_restart_generators(f110_handle *h)
+{
+    HIP_TRY(hipStreamSynchronize(h->noise_stream));
+    h->noise_pending_hi = 0;
+    HIP_TRY(hipDeviceSynchronize());
+    for (int sl = 0; sl < h->noise_slots; sl++) {
+        auto &ns = h->nslots[sl];
+        if (ns.kind != 2) continue;
+        ns.T = 0;
+        HIP_TRY(hipMemcpy(h->d_noise_gen + sl, &ns.seed, sizeof(NoiseGen), hipMemcpyHostToDevice));
+    }
+    noise_recompute_hi(h);
+    return F110_OK;
+}
+
+static int check_noise_slot(f110_handle *h, int slot, const char *who)
+{
+    if (!h) return fail(F110_E_INVALID, "%s: null handle", who);
+    if (slot < 0 || slot >= F110_MAX_NOISE_SLOTS) return fail(F110_E_INDEX, "%s: noise slot %d outside 0..%d", who, slot, F110_MAX_NOISE_SLOTS - 1);
+    return F110_OK;
+}
+
+extern "C" int f110_set_noise_slot(f110_handle *h, int32_t slot, const double *tbl, int64_t T)
+{
+    int rc = check_noise_slot(h, slot, "f110_set_noise_slot");
+    if (rc) return rc;
+    if (T < 1 || !tbl) return fail(F110_E_INVALID, "f110_set_noise_slot: bad table (T >= 1 rows; f110_set_noise_table(h, NULL, 0) switches noise off)");
+    ON_DEVICE(h->cfg.device);
+    const int nb = h->cfg.num_beams;
+    if (h->noise_lo > 0) { h->noise_lo = 0; if ((rc = noise_restart_generators(h))) return rc; } // host-fed rows start at 0
+    HIP_TRY(hipStreamSynchronize(h->noise_stream));
+    HIP_TRY(hipDeviceSynchronize());
+    auto &ns = h->nslots[slot];
+    ns.kind = 1;
+    HIP_TRY(hipMemset(h->d_noise_gen + slot, 0, sizeof(NoiseGen))); // (the slot may have held a generator)
+    ns.rows.assign(tbl, tbl + (size_t)T * nb);
+    ns.T = T;
+    const int slots = std::max(h->noise_slots, slot + 1);
+    const long long cap = std::max(h->noise_cap, pow2_at_least(T));
+    if (slots != h->noise_slots || cap != h->noise_cap || !h->noise_on) {
+        // (first table after "noise off": the one-row table makes way)
+        const bool was_on = h->noise_on;
+        if (!was_on) { h->noise_lo = 0; h->noise_hi = 0; }
+        if ((rc = noise_resize(h, slots, std::max(cap, (long long)2)))) return rc;
+    }
+    {   // stage the rows on the device and interleave them with the side distances
+        DevTemp tmp;
+        double *stage = nullptr;
+        HIP_TRY(tmp.alloc(&stage, (size_t)T * nb));
+        HIP_TRY(hipMemcpy(stage, tbl, (size_t)T * nb * sizeof(double), hipMemcpyHostToDevice));
+        const long long items = (long long)T * nb;
+        hipLaunchKernelGGL(noise_interleave_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, nullptr, (const double *)stage,
+                           (long long)T, nb, h->d_side, h->d_noise, slot, h->noise_cap, h->noise_cap - 1);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipDeviceSynchronize());
+    }
+    noise_recompute_hi(h);
+    return noise_publish(h, nullptr);
+}
+
 extern "C" int f110_set_noise_table(f110_handle *h, const double *tbl, int64_t T)
 {
     if (!h) return fail(F110_E_INVALID, "f110_set_noise_table: null handle");
     if (T < 0 || (T > 0 && !tbl)) return fail(F110_E_INVALID, "f110_set_noise_table: bad table");
+    if (T > 0) return f110_set_noise_slot(h, 0, tbl, T);
+    // noise off: every slot forgets its table / generator
     ON_DEVICE(h->cfg.device);
+    HIP_TRY(hipStreamSynchronize(h->noise_stream));
+    h->noise_pending_hi = 0;
+    for (auto &ns : h->nslots) { ns.kind = 0; ns.rows.clear(); ns.rows.shrink_to_fit(); ns.T = 0; }
     HIP_TRY(hipDeviceSynchronize());
-    h->h_noise.clear();
-    if (T > 0) h->h_noise.assign(tbl, tbl + (size_t)T * h->cfg.num_beams);
-    return rebuild_noise_side(h);
+    HIP_TRY(hipMemset(h->d_noise_gen, 0, sizeof(NoiseGen) * F110_MAX_NOISE_SLOTS));
+    h->noise_on = false; h->noise_lo = 0; h->noise_hi = 0;
+    if (h->multi_noise) { h->multi_noise = false; h->epoch++; }
+    return noise_resize(h, 1, 1);
 }
 
-// {noise row, side distance} interleaved per beam (noise off: one row of zeros)
-static int rebuild_noise_side(f110_handle *h)
+extern "C" int f110_set_noise_generator(f110_handle *h, int32_t slot, const uint64_t *pcg64, double std_dev)
 {
+    int rc = check_noise_slot(h, slot, "f110_set_noise_generator");
+    if (rc) return rc;
+    if (!pcg64 || !(std_dev >= 0) || !std::isfinite(std_dev)) return fail(F110_E_INVALID, "f110_set_noise_generator: bad arguments");
+    if (!(pcg64[2] & 1ull)) return fail(F110_E_INVALID, "f110_set_noise_generator: the PCG64 increment must be odd");
+    ON_DEVICE(h->cfg.device);
+    HIP_TRY(hipStreamSynchronize(h->noise_stream));
+    HIP_TRY(hipDeviceSynchronize());
+    auto &ns = h->nslots[slot];
+    ns.kind = 2;
+    ns.rows.clear();
+    ns.T = 0;
+    {   // the state whose output is the first raw value: one LCG step from NumPy's stored state (pcg64.h: step, then output)
+        typedef unsigned __int128 u128h;
+        const u128h M = ((u128h)0x2360ED051FC65DA4ull << 64) | (u128h)0x4385DF649FCCF645ull;
+        const u128h st = ((u128h)pcg64[1] << 64) | pcg64[0], inc = ((u128h)pcg64[3] << 64) | pcg64[2];
+        const u128h t = st * M + inc;
+        memset(&ns.seed, 0, sizeof(ns.seed));
+        ns.seed.t_lo = (unsigned long long)t; ns.seed.t_hi = (unsigned long long)(t >> 64);
+        ns.seed.inc_lo = pcg64[2]; ns.seed.inc_hi = pcg64[3];
+        ns.seed.std = std_dev; ns.seed.rows = 0; ns.seed.on = 1;
+    }
+    const int slots = std::max(h->noise_slots, slot + 1);
+    if (slots != h->noise_slots || !h->noise_on || h->noise_cap < 2) {
+        if (!h->noise_on) { h->noise_lo = 0; h->noise_hi = 0; }
+        if ((rc = noise_resize(h, slots, std::max(h->noise_cap, (long long)F110_NOISE_INITIAL_ROWS)))) return rc;
+    }
+    // a new stream in one slot: every generator slot goes back to row 0, so that all of them stand at the same row again
+    h->noise_lo = 0;
+    h->noise_on = true;
+    if ((rc = noise_restart_generators(h))) return rc;
+    return noise_publish(h, nullptr);
+}
+
+extern "C" int f110_noise_prefetch(f110_handle *h, int64_t rows)
+{
+    if (!h) return fail(F110_E_INVALID, "f110_noise_prefetch: null handle");
+    if (!h->noise_on || !noise_has_generators(h) || h->noise_pending_hi) return F110_OK;
+    long long have = 0x7fffffffffffffffll;
+    for (int sl = 0; sl < h->noise_slots; sl++)
+        if (h->nslots[sl].kind == 2) have = std::min(have, h->nslots[sl].T);
+    if (rows <= have) return F110_OK;
+    const long long r1 = (rows + 63) & ~63ll;
+    if (r1 - h->noise_lo > h->noise_cap) return F110_OK; // needs a larger table: f110_noise_ensure grows it when the rows are due
+    ON_DEVICE(h->cfg.device);
+    // The generator appends rows have .. r1-1 into ring places whose previous tenants lie below the floor: nothing that
+    // is enqueued anywhere reads them, so no ordering against the caller's stream is needed.
+    if (int rc = noise_launch_generator(h, r1, h->noise_stream)) return rc;
+    HIP_TRY(hipEventRecord(h->noise_ev, h->noise_stream));
+    h->noise_pending_hi = r1;
+    return F110_OK;
+}
+
+extern "C" int f110_noise_ensure(f110_handle *h, int64_t rows, void *stream)
+{
+    if (!h) return fail(F110_E_INVALID, "f110_noise_ensure: null handle");
+    if (!h->noise_on || rows <= h->noise_hi) return F110_OK;
+    if (int rc = check_device(h, "f110_noise_ensure")) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    noise_reap(h, false);
+    int rc = noise_absorb_pending(h, st);
+    if (rc) return rc;
+    if (rows <= h->noise_hi) return F110_OK;
+    for (int sl = 0; sl < h->noise_slots; sl++)
+        if (h->nslots[sl].kind == 1 && h->nslots[sl].T < rows)
+            return fail(F110_E_INVALID, "f110_noise_ensure: noise slot %d is a host table of %lld rows, %lld are needed (upload a longer "
+                        "table with f110_set_noise_slot, or use f110_set_noise_generator)", sl, h->nslots[sl].T, (long long)rows);
+    const long long r1 = (rows + 63) & ~63ll;
+    if (r1 - h->noise_lo > h->noise_cap) // the ring is too small for rows lo .. r1-1: a larger one (cold path, synchronises)
+        if ((rc = noise_resize(h, h->noise_slots, pow2_at_least(std::max(2 * h->noise_cap, r1 - h->noise_lo))))) return rc;
+    if ((rc = noise_launch_generator(h, r1, st))) return rc;
+    for (int sl = 0; sl < h->noise_slots; sl++)
+        if (h->nslots[sl].kind == 2) h->nslots[sl].T = r1;
+    noise_recompute_hi(h);
+    return noise_publish(h, st);
+}
+
+extern "C" int f110_noise_set_floor(f110_handle *h, int64_t lo, void *stream)
+{
+    if (!h || lo < 0) return fail(F110_E_INVALID, "f110_noise_set_floor: bad arguments");
+    if (!h->noise_on || lo == h->noise_lo) return F110_OK;
+    if (int rc = check_device(h, "f110_noise_set_floor")) return rc;
+    if (lo > h->noise_lo) {
+        for (int sl = 0; sl < h->noise_slots; sl++)
+            if (h->nslots[sl].kind == 1) return fail(F110_E_INVALID, "f110_noise_set_floor: noise slot %d is a host table (rows are only dropped from generated noise)", sl);
+        if (lo > h->noise_hi) return fail(F110_E_INVALID, "f110_noise_set_floor: floor %lld above the %lld rows produced", (long long)lo, h->noise_hi);
+        h->noise_lo = lo;
+        return noise_publish(h, (hipStream_t)stream);
+    }
+    // the floor comes down (a car was reset while others run on): the dropped rows are produced again from the seeds
+    h->noise_lo = lo;
+    int rc = noise_restart_generators(h);
+    if (rc) return rc;
+    return noise_publish(h, (hipStream_t)stream);
+}
+
+extern "C" int f110_noise_info(f110_handle *h, int64_t *lo, int64_t *hi, int64_t *cap, int32_t *slots, int64_t *bytes)
+{
+    if (!h) return fail(F110_E_INVALID, "f110_noise_info: null handle");
+    if (lo) *lo = h->noise_lo;
+    if (hi) *hi = h->noise_on ? h->noise_hi : 0; // (rows a prefetch is still producing are not counted: f110_noise_ensure makes them readable)
+    if (cap) *cap = h->noise_cap;
+    if (slots) *slots = h->noise_slots;
+    if (bytes) {
+        long long b = (long long)h->noise_slots * h->noise_cap * h->cfg.num_beams * (long long)sizeof(double2);
+        noise_reap(h, false);
+        *bytes = b * (1 + (long long)h->retired.size());
+    }
+    return F110_OK;
+}
+
+extern "C" int f110_noise_read(f110_handle *h, int32_t slot, int64_t row0, int64_t n_rows, double *out)
+{
+    int rc = check_noise_slot(h, slot, "f110_noise_read");
+    if (rc) return rc;
+    if (!out || n_rows < 0) return fail(F110_E_INVALID, "f110_noise_read: bad arguments");
+    ON_DEVICE(h->cfg.device);
+    HIP_TRY(hipStreamSynchronize(h->noise_stream));
+    HIP_TRY(hipDeviceSynchronize());
+    const long long hi = h->noise_on ? std::max(h->noise_hi, h->noise_pending_hi) : 0;
+    if (slot >= h->noise_slots || row0 < h->noise_lo || row0 + n_rows > hi)
+        return fail(F110_E_INDEX, "f110_noise_read: rows %lld..%lld of slot %d; the table holds rows %lld..%lld of %d slots", (long long)row0,
+                    (long long)(row0 + n_rows - 1), slot, h->noise_lo, hi - 1, h->noise_slots);
     const int nb = h->cfg.num_beams;
-    const long long T = (long long)(h->h_noise.size() / nb);
-    const long long rows = T > 0 ? T : 1;
-    std::vector<double2> ns((size_t)rows * nb);
-    for (long long t = 0; t < rows; t++)
-        for (int i = 0; i < nb; i++) {
-            ns[(size_t)t * nb + i].x = T > 0 ? h->h_noise[(size_t)t * nb + i] : 0.0;
-            ns[(size_t)t * nb + i].y = h->h_side[i];
+    std::vector<double2> tmp((size_t)nb);
+    for (long long r = row0; r < row0 + n_rows; r++) {
+        HIP_TRY(hipMemcpy(tmp.data(), h->d_noise + ((size_t)slot * h->noise_cap + (size_t)(r & (h->noise_cap - 1))) * nb, (size_t)nb * sizeof(double2),
+                          hipMemcpyDeviceToHost));
+        for (int b = 0; b < nb; b++) out[(size_t)(r - row0) * nb + b] = tmp[b].x;
+    }
+    return F110_OK;
+}
+
+extern "C" int f110_assign_noise(f110_handle *h, const int32_t *slot_of_env)
+{
+    if (!h) return fail(F110_E_INVALID, "f110_assign_noise: null handle");
+    const int B = h->cfg.num_envs;
+    std::vector<int32_t> m(B, 0);
+    bool multi = false;
+    if (slot_of_env)
+        for (int e = 0; e < B; e++) {
+            const int k = slot_of_env[e];
+            if (k < 0 || k >= h->noise_slots || (h->noise_on && h->nslots[k].kind == 0))
+                return fail(F110_E_INDEX, "f110_assign_noise: env %d uses noise slot %d, which holds neither a table nor a generator", e, k);
+            m[e] = k;
+            multi = multi || k != 0;
         }
     ON_DEVICE(h->cfg.device);
-    HIP_TRY(hipDeviceSynchronize()); // enqueued steps may still read the old table
-    if (h->d_noise_side) { (void)hipFree(h->d_noise_side); h->d_noise_side = nullptr; }
-    HIP_TRY(hipMalloc((void **)&h->d_noise_side, ns.size() * sizeof(double2)));
-    HIP_TRY(hipMemcpy(h->d_noise_side, ns.data(), ns.size() * sizeof(double2), hipMemcpyHostToDevice));
-    h->noise_T = T;
+    HIP_TRY(hipDeviceSynchronize());
+    if (!h->d_env_noise) HIP_TRY(hipMalloc((void **)&h->d_env_noise, sizeof(int32_t) * B));
+    HIP_TRY(hipMemcpy(h->d_env_noise, m.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice));
+    h->multi_noise = multi;
     h->epoch++;
+    return F110_OK;
+}
+
+extern "C" int f110_device_errors(f110_handle *h, uint32_t *flags)
+{
+    if (!h || !flags) return fail(F110_E_INVALID, "f110_device_errors: null argument");
+    ON_DEVICE(h->cfg.device);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(flags, h->d_err, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (*flags) HIP_TRY(hipMemset(h->d_err, 0, sizeof(uint32_t)));
     return F110_OK;
 }
 
@@ -897,7 +1364,7 @@ static int check_scan_args(const ScanArgs &a, const char *who)
     if (a.n_cars < 1 || a.agents < 1 || a.scan.nb < 2 || a.scan.nb > MAX_CHUNKS * 64) return fail(F110_E_INVALID, "%s: %d cars, %d agents, %d beams", who, a.n_cars, a.agents, a.scan.nb);
     if (!a.maps || !a.scan.cs || a.scan.cs_len < a.scan.theta_dis || !a.chunk_beam0 || !a.pose_src) return fail(F110_E_INVALID, "%s: a table of the scan is missing (maps / {cos,sin} LUT / chunk order / poses)", who);
     if (!a.out_f32 && !a.out_f64) return fail(F110_E_INVALID, "%s: no output buffer", who);
-    if (a.state && (!a.noise_step || !a.noise_side || a.noise_T < 1 || !a.beam_cosines || !a.in_collision || !a.pending_reset))
+    if (a.state && (!a.noise_step || !a.noise || !a.beam_cosines || !a.in_collision || !a.pending_reset))
         return fail(F110_E_INVALID, "%s: a buffer of the step's scan is missing (noise / beam cosines / in_collision / pending_reset)", who);
     if (!a.state && a.reset_only) return fail(F110_E_INVALID, "%s: reset_only without the step's buffers", who);
     return F110_OK;
@@ -978,7 +1445,7 @@ static void fill_scan_args(const f110_handle *h, ScanArgs &s, int reset_only)
     s.maps = h->d_maps; s.env_map = h->multi ? h->d_env_map : nullptr; s.scan = scan_dev(h); s.n_cars = c.num_envs * c.num_agents; s.agents = c.num_agents;
     s.pose_src = b.state; s.pose_stride = 7; s.yaw_off = 4;
     s.state = b.state; s.noise_step = b.noise_step; s.chunk_beam0 = h->d_chunk0;
-    s.noise_side = h->d_noise_side; s.noise_T = h->noise_T > 0 ? h->noise_T : 1;
+    s.noise = h->d_noise_desc; s.env_noise = h->multi_noise ? h->d_env_noise : nullptr; s.dev_err = h->d_err;
     s.beam_cosines = h->d_beam_cosines; s.ttc_thresh = c.ttc_thresh;
     s.in_collision = b.in_collision; s.pending_reset = b.pending_reset; s.reset_only = reset_only;
     s.out_f32 = b.scans; s.out_f64 = b.scans_f64; s.lookups = b.lookups;
@@ -1009,7 +1476,7 @@ static int run_step(f110_handle *h, const double *actions, int reset_only, const
         DynArgs d;
         d.n_cars = N; d.agents = c.num_agents; d.state = b.state; d.steer_buf = b.steer_buf; d.steer_cnt = b.steer_cnt;
         d.noise_step = b.noise_step; d.actions = actions; d.spawn = b.spawn; d.pending_reset = b.pending_reset;
-        d.reset_only = reset_only; d.pose_snap = b.pose_snap; d.in_collision = b.in_collision; d.agent_params = h->d_agent_params;
+        d.reset_only = reset_only; d.pose_snap = b.pose_snap; d.in_collision = b.in_collision; d.params = h->d_params; d.env_params = h->multi_params ? h->d_env_params : nullptr;
         d.time_step = c.timestep; d.integrator = c.integrator;
         if ((rc = emit(st, (const void *)&dynamics_kernel, dim3((N + 255) / 256), dim3(256), 0, d))) return rc;
     }
@@ -1044,7 +1511,7 @@ static int run_step(f110_handle *h, const double *actions, int reset_only, const
     if (c.num_agents > 1) {
         OppArgs o;
         o.n_cars = N; o.agents = c.num_agents; o.nb = c.num_beams; o.state = b.state; o.pose_snap = b.pose_snap;
-        o.in_collision = b.in_collision; o.scan_angles = h->d_scan_angles; o.beam_cs = h->d_beam_cs; o.agent_params = h->d_agent_params;
+        o.in_collision = b.in_collision; o.scan_angles = h->d_scan_angles; o.beam_cs = h->d_beam_cs; o.params = h->d_params; o.env_params = h->multi_params ? h->d_env_params : nullptr;
         o.pending_reset = b.pending_reset; o.reset_only = reset_only; o.scans32 = b.scans; o.scans64 = b.scans_f64;
         o.pairs = h->d_opp_pairs;
         const int npairs = N * (c.num_agents - 1);
@@ -1058,24 +1525,9 @@ static int run_step(f110_handle *h, const double *actions, int reset_only, const
     e.in_collision = b.in_collision; e.collisions = b.collisions; e.collision_idx = b.collision_idx;
     e.start_rot = b.start_rot; e.near_start = b.near_start; e.toggles = b.toggles; e.lap_counts = b.lap_counts;
     e.lap_times = b.lap_times; e.current_time = b.current_time; e.pending_reset = b.pending_reset; e.done = b.done; e.checkpoint_done = b.checkpoint_done;
-    e.time_step = c.timestep; e.car_length = h->params.v[P_LENGTH]; e.car_width = h->params.v[P_WIDTH];
+    e.time_step = c.timestep; e.params = h->d_params; e.env_params = h->multi_params ? h->d_env_params : nullptr;
     return emit(st, (const void *)&env_kernel, dim3((c.num_envs + 127) / 128), dim3(128), 0, e);
 }
-
-// Launches go to the caller's stream, which belongs to the calling thread's CURRENT device: it must be the handle's.
-// (Checked, not switched: hipGetDevice is a thread-local read; switching would cost two runtime calls per step and
-// still leave the caller's stream on the wrong device.)
-static int check_current_device(int dev, const char *who)
-{
-    int cur = -1;
-    HIP_TRY(hipGetDevice(&cur));
-    if (cur != dev)
-        return fail(F110_E_INVALID, "%s: the handle lives on device %d but the calling thread's current device is %d; make the "
-                    "handle's device current (hipSetDevice / torch.cuda.device) and pass a stream of that device", who, dev, cur);
-    return F110_OK;
-}
-
-static int check_device(const f110_handle *h, const char *who) { return check_current_device(h->cfg.device, who); }
 
 static int check_ready(f110_handle *h, const char *who, bool launches_on_callers_stream = true)
 {
@@ -1416,7 +1868,7 @@ extern "C" int f110_scan(f110_handle *h, const double *poses, int32_t n, double 
     memset(&s, 0, sizeof(s));
     s.maps = h->d_maps; s.scan = scan_dev(h); s.n_cars = n; s.agents = 1;
     s.pose_src = poses; s.pose_stride = 3; s.yaw_off = 2;
-    s.out_f32 = out32; s.out_f64 = out64; s.lookups = lookups; s.noise_T = 1; s.chunk_beam0 = h->d_chunk0;
+    s.out_f32 = out32; s.out_f64 = out64; s.lookups = lookups; s.chunk_beam0 = h->d_chunk0;
     Sink k;
     k.st = (hipStream_t)stream;
     return launch_scan(h, s, k);
@@ -1432,7 +1884,7 @@ extern "C" int f110_update_pose(f110_handle *h, double *state, double *steer_buf
     DynArgs d;
     memset(&d, 0, sizeof(d));
     d.n_cars = n; d.agents = 1; d.state = state; d.steer_buf = steer_buf; d.steer_cnt = steer_cnt; d.actions = actions;
-    d.agent_params = h->d_agent_params; d.time_step = h->cfg.timestep; d.integrator = h->cfg.integrator;
+    d.params = h->d_params; d.time_step = h->cfg.timestep; d.integrator = h->cfg.integrator;
     hipLaunchKernelGGL(dynamics_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, d);
     HIP_TRY(hipGetLastError());
     return F110_OK;
@@ -1445,7 +1897,7 @@ extern "C" int f110_vehicle_dynamics(f110_handle *h, const double *x, const doub
     if (!h || !x || !u || !f || n < 0) return fail(F110_E_INVALID, "f110_vehicle_dynamics: bad arguments");
     if (int rc = check_device(h, "f110_vehicle_dynamics")) return rc;
     hipLaunchKernelGGL(rhs_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, u, n, kinematic,
-                       h->d_agent_params, f);
+                       h->d_params, f);
     HIP_TRY(hipGetLastError());
     return F110_OK;
 }
@@ -1456,7 +1908,7 @@ extern "C" int f110_get_vertices(f110_handle *h, const double *poses, int32_t n,
     if (!h || !poses || !verts || n < 0) return fail(F110_E_INVALID, "f110_get_vertices: bad arguments");
     if (int rc = check_device(h, "f110_get_vertices")) return rc;
     hipLaunchKernelGGL(vertices_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, poses, n,
-                       h->params.v[P_LENGTH], h->params.v[P_WIDTH], verts);
+                       h->h_params[0].v[P_LENGTH], h->h_params[0].v[P_WIDTH], verts);
     HIP_TRY(hipGetLastError());
     return F110_OK;
 }

@@ -7,6 +7,7 @@
 // plus small function-level kernels used by the parity entry points.
 #pragma once
 #include "f110_device.h"
+#include "f110_noise.h"
 
 #pragma clang fp contract(off)
 
@@ -25,6 +26,8 @@ __device__ inline int med3_i32(int x, int lo, int hi)
 __device__ inline unsigned long long vote(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
 constexpr int WAVE = 64;
+// bits of the device error word (f110_device_errors; include/f110_hip.h F110_DEVERR_*)
+constexpr uint32_t DEVERR_NOISE_WINDOW = 1u, DEVERR_BOUNDS = 2u;
 constexpr int TL_MAX_WAVES = 8; // (diagnostics builds: per-wave stamps of a workgroup)
 #ifndef F110_SCAN_WAVES
 #define F110_SCAN_WAVES 2
@@ -228,8 +231,10 @@ struct ScanArgs {
     // full-step extras (all NULL for the function-level scan)
     const double *state;         // [N,7]: velocity for the iTTC test
     const int32_t *noise_step;   // [N]
-    const double2 *noise_side;   // [T,nb] {noise of row t, side distance} interleaved: one 16-B gather per finished beam
-    long long noise_T;
+    const NoiseDesc *noise;      // device descriptor of the noise table ({noise of a row, side distance} pairs: one 16-B gather
+                                 // per beam taken); read once per car, its address is fixed for the handle's life
+    const int32_t *env_noise;    // [B] noise slot (= seed) of every env, or NULL (all envs on slot 0)
+    uint32_t *dev_err;           // device error word (f110_device_errors): F110_DEVERR_* bits, or NULL
     const double *beam_cosines;  // [nb]
     double ttc_thresh;
     uint8_t *in_collision;       // [N]
@@ -334,7 +339,19 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
     // iTTC hit needs 0 <= (v - side)/(vel*cos) < thresh, hence |v - side| < thresh*|vel|:
     // only such candidate beams pay the exact fp64 division
     const double cand = a.ttc_thresh * fabs(vel) * 1.000000001;
-    const double2 *__restrict__ ns = STEP ? a.noise_side + (size_t)((long long)a.noise_step[car] % a.noise_T) * nb : nullptr;
+    const double2 *__restrict__ ns = nullptr;
+    if (STEP) {
+        // the car's noise row: row `scans since its reset` of its env's slot (a ring of nd.cap rows per slot)
+        const NoiseDesc nd = *rare->noise;
+        const long long row = (long long)a.noise_step[car];
+        const int32_t *en = rare->env_noise;
+        const long long slot = en ? (long long)en[car / a.agents] : 0ll;
+        if (__builtin_expect(row < nd.lo || row >= nd.hi, 0)) {
+            // the host keeps the table ahead of every car (Engine._ensure_noise); a row outside it is reported, never silent
+            if (lane == 0 && rare->dev_err) atomicOr(rare->dev_err, DEVERR_NOISE_WINDOW);
+        }
+        ns = nd.base + (size_t)(slot * nd.cap + (row & nd.mask)) * (size_t)nb;
+    }
     float *o32 = a.out_f32 ? a.out_f32 + (size_t)car * nb : nullptr;
     double *o64 = a.out_f64 ? a.out_f64 + (size_t)car * nb : nullptr;
     bool hit = false;
@@ -485,7 +502,8 @@ struct OppArgs {
     const uint8_t *in_collision; // [N]
     const double *scan_angles;
     const double2 *beam_cs;   // [nb] {cos, sin}(scan_angles)
-    const Params *agent_params; // [agents]: a car sizes its opponents with its OWN params (base_classes.py:221)
+    const Params *params;     // [slots, 1 + agents] (see DynArgs): a car sizes its opponents with its OWN params (base_classes.py:221)
+    const int32_t *env_params;// [B] or NULL
     const uint8_t *pending_reset;
     int reset_only;
     OppPair *pairs;           // [N, agents-1] scratch owned by the handle
@@ -507,7 +525,7 @@ __global__ __launch_bounds__(128) void opp_setup_kernel(OppArgs a)
     // an iTTC hit zeroes the yaw before the ray cast (base_classes.py:245); env_kernel applies it
     const double px = st[0], py = st[1], pyaw = a.in_collision[car] ? 0.0 : st[4];
     const double *op = a.pose_snap + (size_t)(a0 + j) * 3;
-    const Params &P = a.agent_params[self];
+    const Params &P = a.params[(size_t)(a.env_params ? a.env_params[env] : 0) * (a.agents + 1) + 1 + self];
     double verts[4][2];
     get_vertices(op[0], op[1], op[2], P.v[P_LENGTH], P.v[P_WIDTH], verts);
     // laser_models.py:283-315
@@ -640,7 +658,11 @@ struct DynArgs {
     int reset_only;
     double *pose_snap;    // [N,3] or NULL
     uint8_t *in_collision;// [N] or NULL: cleared here, set by scan_kernel
-    const Params *agent_params; // [agents] device: RaceCar.params of agent i (base_classes.py:84,169)
+    // Vehicle parameters: [slots, 1 + agents] -- per params slot (= the `params` one reference env was constructed with,
+    // f110_env.py:125-128) entry 0 is Simulator.params (GJK vertices, base_classes.py:542), entry 1 + i RaceCar.params of
+    // agent i (:84,169, changed by update_params :507-527)
+    const Params *params;
+    const int32_t *env_params;  // [B] params slot of every env, or NULL (all envs on slot 0)
     double time_step;
     int integrator;
 };
@@ -710,7 +732,7 @@ __global__ __launch_bounds__(256) void dynamics_kernel(DynArgs a)
         steer = a.actions[(size_t)car * 2];
         speed = a.actions[(size_t)car * 2 + 1];
     }
-    const Params P = a.agent_params[car % a.agents];
+    const Params P = a.params[(size_t)(a.env_params ? a.env_params[env] : 0) * (a.agents + 1) + 1 + car % a.agents];
     update_pose(st, sb, sc, steer, speed, P, a.time_step, a.integrator);
 #pragma unroll
     for (int i = 0; i < 7; i++) a.state[(size_t)car * 7 + i] = st[i];
@@ -744,7 +766,9 @@ struct EnvArgs {
     uint8_t *pending_reset;   // [B]
     uint8_t *done;            // [B]
     uint8_t *checkpoint_done; // [N] or NULL
-    double time_step, car_length, car_width;
+    const Params *params;     // [slots, 1 + agents] (see DynArgs): entry 0 of the env's slot sizes the GJK quads
+    const int32_t *env_params;// [B] or NULL
+    double time_step;
 };
 
 // collision_models.py:185-212 on A <= 8 quads held in registers/scratch
@@ -837,7 +861,8 @@ __global__ __launch_bounds__(128) void env_kernel(EnvArgs a)
     if (a.reset_only && !pend) return;
     const int A = a.agents, c0 = env * A;
     // Simulator.check_collision (base_classes.py:529-543) on the post-integration poses
-    collision_multiple_dev(a.pose_snap + (size_t)c0 * 3, A, a.car_length, a.car_width,
+    const Params &SP = a.params[(size_t)(a.env_params ? a.env_params[env] : 0) * (A + 1)]; // Simulator.params (:542)
+    collision_multiple_dev(a.pose_snap + (size_t)c0 * 3, A, SP.v[P_LENGTH], SP.v[P_WIDTH],
                            a.collisions + c0, a.collision_idx + c0);
     for (int i = 0; i < A; i++) {
         if (a.in_collision[c0 + i]) {
@@ -874,11 +899,11 @@ __global__ __launch_bounds__(128) void env_kernel(EnvArgs a)
 
 // ------------------------------------------------------------------ function-level kernels
 // dynamic_models.py:91-121 / :124-176 right-hand sides (the reference's KAT surface)
-__global__ void rhs_kernel(const double *x, const double *u, int n, int kinematic, const Params *agent_params, double *f)
+__global__ void rhs_kernel(const double *x, const double *u, int n, int kinematic, const Params *params, double *f)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const Params P = agent_params[0];
+    const Params P = params[1]; // slot 0, agent 0
     double xs[7], fs[7];
     for (int k = 0; k < 7; k++) xs[k] = x[(size_t)i * 7 + k];
     if (kinematic) {

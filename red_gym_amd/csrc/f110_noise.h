@@ -1,0 +1,203 @@
+// f110_noise.h -- the lidar noise of the step path, generated on the GPU.
+//
+// Reference: every scan of every car adds `rng.normal(0., 0.01, size=num_beams)` (laser_models.py:450-452) drawn from a
+// per-car `np.random.default_rng(seed)` that is re-created at every reset (base_classes.py:117,202).  All cars of an env
+// share the seed, so the row a car adds depends only on (seed, scans since its reset): the rows of one seed are kept
+// ONCE per seed ("noise slot") in a device table indexed by each car's own counter, and produced here, on the device,
+// by a bit-level restatement of what NumPy executes for that call:
+//   * PCG64 (numpy/random/src/pcg64/pcg64.h, pcg_setseq_128_xsl_rr_64): 128-bit LCG step, XSL-RR output of the new state;
+//   * random_standard_normal (numpy/random/src/distributions/distributions.c): 256-layer ziggurat -- 99.3 % of the draws
+//     are one table compare; the wedge test uses exp(), the tail (|x| > 3.654, 0.026 % of the draws) log1p();
+//   * random_normal: loc + scale * x.
+// The stream is sequential (a draw consumes one raw value, or more after a rejection), so ONE WAVEFRONT per seed walks it:
+// lane j holds the generator state of raw position p + j (LCG jump-ahead), all lanes test their candidate at once, the
+// run of leading fast accepts is written as consecutive beams, the first rejected candidate -- if any -- is resolved by
+// the sequential rule on a broadcast state, and the window is re-based by the number of raw values consumed (lanes that
+// fall off the front jump 64 positions ahead, then the wave rotates).  Exactness: every accepted value outside the tail
+// is the product of an integer and a table entry (no library call); the tail's log1p comes from the device math library
+// and may differ from glibc's by an ulp of a 1e-2-scaled term (tests/test_gpu_noise.py counts how often).
+#pragma once
+#include "f110_device.h"
+#include "f110_ziggurat.h"
+
+#pragma clang fp contract(off)
+
+namespace f110 {
+
+typedef unsigned __int128 u128;
+
+// What the scan kernel needs to find a car's noise row.  Lives in device memory at an address that never changes for
+// the handle's life (the kernel's by-value arguments -- and therefore captured hipGraphs -- survive every growth).
+// Row r of slot s: base[(s * cap + (r & mask)) * num_beams + beam] = {noise, side distance of the beam}; rows lo <= r < hi
+// are present (a ring once lo > 0); noise off: cap = 1, one row of zeros.
+struct NoiseDesc {
+    const double2 *base;
+    long long mask, cap, lo, hi;
+};
+
+// generator of one slot: t = the LCG state whose output is the NEXT raw value of the stream
+struct NoiseGen {
+    unsigned long long t_lo, t_hi, inc_lo, inc_hi;
+    double std;
+    long long rows;   // rows produced so far (the stream stands at the start of row `rows`)
+    int on, pad;
+};
+
+__device__ inline u128 pcg_mult() { return ((u128)0x2360ED051FC65DA4ull << 64) | (u128)0x4385DF649FCCF645ull; } // PCG_DEFAULT_MULTIPLIER_128
+
+__device__ inline unsigned long long pcg_out(u128 s) // pcg_output_xsl_rr_128_64
+{
+    const unsigned long long hi = (unsigned long long)(s >> 64), lo = (unsigned long long)s;
+    const unsigned long long x = hi ^ lo;
+    const unsigned rot = (unsigned)(hi >> 58);
+    return (x >> rot) | (x << ((0u - rot) & 63u));
+}
+
+__device__ inline double pcg_double(unsigned long long raw) { return (double)(raw >> 11) * (1.0 / 9007199254740992.0); }
+
+__device__ inline u128 shfl128(u128 v, int src)
+{
+    unsigned w0 = (unsigned)v, w1 = (unsigned)(v >> 32), w2 = (unsigned)(v >> 64), w3 = (unsigned)(v >> 96);
+    w0 = (unsigned)__shfl((int)w0, src); w1 = (unsigned)__shfl((int)w1, src);
+    w2 = (unsigned)__shfl((int)w2, src); w3 = (unsigned)__shfl((int)w3, src);
+    return ((u128)w3 << 96) | ((u128)w2 << 64) | ((u128)w1 << 32) | (u128)w0;
+}
+
+__device__ inline unsigned long long shfl64(unsigned long long v, int src)
+{
+    const unsigned lo = (unsigned)__shfl((int)(unsigned)v, src), hi = (unsigned)__shfl((int)(unsigned)(v >> 32), src);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+struct NoiseGenArgs {
+    NoiseGen *gen;        // [slots]
+    double2 *base;        // the table being filled
+    long long mask, cap;
+    long long lo;         // rows below lo are generated (the stream must advance) but not stored
+    long long r1;         // every active slot is brought to r1 rows
+    int nb;
+    const double *side;   // [nb] side distances (interleaved with the noise, see NoiseDesc)
+};
+
+// One wavefront per noise slot (grid = slots).
+__global__ __launch_bounds__(64) void noise_rows_kernel(NoiseGenArgs a)
+{
+    __shared__ unsigned long long s_ki[256];
+    __shared__ double s_wi[256], s_fi[256];
+    const int lane = threadIdx.x, slot = blockIdx.x;
+    const NoiseGen g = a.gen[slot];
+    if (!g.on || g.rows >= a.r1) return; // (uniform)
+    for (int i = lane; i < 256; i += 64) { s_ki[i] = ZIG_KI[i]; s_wi[i] = ZIG_WI[i]; s_fi[i] = ZIG_FI[i]; }
+    __syncthreads();
+    const u128 M = pcg_mult(), inc = ((u128)g.inc_hi << 64) | (u128)g.inc_lo;
+    // 64 steps at once: s -> A * s + C
+    u128 A = 1, C = 0;
+    for (int i = 0; i < 64; i++) { A *= M; C = C * M + inc; }
+    u128 T = ((u128)g.t_hi << 64) | (u128)g.t_lo;
+    for (int i = 0; i < lane; i++) T = T * M + inc; // lane j: the state of raw position p + j
+    const double std = g.std;
+    const int nb = a.nb;
+    for (long long row = g.rows; row < a.r1; row++) {
+        const bool keep = row >= a.lo;
+        double2 *dst = a.base + ((size_t)slot * (size_t)a.cap + (size_t)(row & a.mask)) * (size_t)nb;
+        int o = 0; // beams of this row produced so far
+        while (o < nb) {
+            // distributions.c random_standard_normal: r = next_uint64; idx = r & 0xff; r >>= 8; sign = r & 1;
+            // rabs = (r >> 1) & 0x000fffffffffffff; x = rabs * wi[idx]; if (sign) x = -x; if (rabs < ki[idx]) return x;
+            unsigned long long r = pcg_out(T);
+            const int idx = (int)(r & 0xffull);
+            r >>= 8;
+            const bool neg = (r & 1ull) != 0;
+            const unsigned long long rabs = (r >> 1) & 0x000fffffffffffffull;
+            double x = (double)rabs * s_wi[idx];
+            if (neg) x = -x;
+            const bool fast = rabs < s_ki[idx];
+            const unsigned long long bad = __builtin_amdgcn_ballot_w64(!fast);
+            const int nfast = bad ? (int)__builtin_ctzll(bad) : 64; // leading lanes whose candidate is accepted at once
+            const int m = nfast < nb - o ? nfast : nb - o;
+            if (lane < m && keep) dst[o + lane] = make_double2(0.0 + std * x, a.side[o + lane]); // random_normal: loc + scale * x
+            o += m;
+            int consumed = m;
+            if (o < nb && m == nfast && nfast < 64) {
+                // lane nfast's candidate takes the slow path: the sequential rule on a broadcast copy of its state
+                const int f = nfast;
+                u128 Q = shfl128(T, f);
+                const int idx_f = __shfl(idx, f);
+                const unsigned long long rabs_f = shfl64(rabs, f);
+                const double x_f = __longlong_as_double((long long)shfl64((unsigned long long)__double_as_longlong(x), f));
+                int extra = 0;
+                bool emit;
+                double val;
+                if (idx_f == 0) {
+                    // tail: xx = -inv_r * log1p(-U), yy = -log1p(-U) until yy + yy > xx * xx
+                    for (;;) {
+                        Q = Q * M + inc; const double u1 = pcg_double(pcg_out(Q));
+                        Q = Q * M + inc; const double u2 = pcg_double(pcg_out(Q));
+                        extra += 2;
+                        const double xx = -ZIG_NOR_INV_R * log1p(-u1);
+                        const double yy = -log1p(-u2);
+                        if (yy + yy > xx * xx) { val = ((rabs_f >> 8) & 1ull) ? -(ZIG_NOR_R + xx) : ZIG_NOR_R + xx; break; }
+                    }
+                    emit = true;
+                } else {
+                    // wedge: ((fi[idx-1] - fi[idx]) * U + fi[idx]) < exp(-0.5 * x * x) ? return x : draw again
+                    Q = Q * M + inc; const double u = pcg_double(pcg_out(Q));
+                    extra = 1;
+                    emit = ((s_fi[idx_f - 1] - s_fi[idx_f]) * u + s_fi[idx_f]) < exp(-0.5 * x_f * x_f);
+                    val = x_f;
+                }
+                if (emit) {
+                    if (lane == 0 && keep) dst[o] = make_double2(0.0 + std * val, a.side[o]);
+                    o += 1;
+                }
+                consumed = f + 1 + extra;
+            }
+            // re-base the window: lane i must hold the state of raw position p + consumed + i
+            while (consumed >= 64) { T = A * T + C; consumed -= 64; }
+            if (consumed > 0) {
+                if (lane < consumed) T = A * T + C;
+                T = shfl128(T, (lane + consumed) & 63);
+            }
+        }
+    }
+    if (lane == 0) {
+        a.gen[slot].t_lo = (unsigned long long)T;
+        a.gen[slot].t_hi = (unsigned long long)(T >> 64);
+        a.gen[slot].rows = a.r1;
+    }
+}
+
+// host-fed slot: plain fp64 rows [T, nb] (device staging copy) -> {noise, side} pairs of rows 0 .. T-1
+__global__ void noise_interleave_kernel(const double *rows, long long T, int nb, const double *side, double2 *base, int slot,
+                                        long long cap, long long mask)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T * nb) return;
+    const long long r = i / nb;
+    const int b = (int)(i - r * nb);
+    base[((size_t)slot * (size_t)cap + (size_t)(r & mask)) * (size_t)nb + b] = make_double2(rows ? rows[i] : 0.0, side[b]);
+}
+
+// the side distances changed (f110_set_tables): rewrite the second component of every pair
+__global__ void noise_set_side_kernel(double2 *base, long long total_rows, int nb, const double *side)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total_rows * nb) return;
+    base[i].y = side[(int)(i % nb)];
+}
+
+// growth: rows lo .. hi-1 of every slot move to their places in a larger ring
+__global__ void noise_move_kernel(const double2 *src, long long scap, long long smask, double2 *dst, long long dcap,
+                                  long long dmask, int slots, long long lo, long long hi, int nb)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long per = (hi - lo) * nb;
+    if (i >= per * slots) return;
+    const int s = (int)(i / per);
+    const long long k = i - (long long)s * per;
+    const long long r = lo + k / nb;
+    const int b = (int)(k % nb);
+    dst[((size_t)s * (size_t)dcap + (size_t)(r & dmask)) * (size_t)nb + b] = src[((size_t)s * (size_t)scap + (size_t)(r & smask)) * (size_t)nb + b];
+}
+
+} // namespace f110

@@ -54,7 +54,9 @@ def beam_tables(num_beams, fov, params):
 
 class NoiseTable(object):
     """Rows of `default_rng(seed).normal(0, std, num_beams)` (laser_models.py:451,
-    base_classes.py:202): every car draws one row per scan since its reset."""
+    base_classes.py:202): every car draws one row per scan since its reset.  The host-side source of the noise
+    (Engine(noise_source='numpy')): NumPy itself draws, the rows are uploaded.  The default source produces the same
+    rows on the device (csrc/f110_noise.h)."""
 
     def __init__(self, seed, num_beams, std_dev=0.01):
         self.seed, self.num_beams, self.std_dev = seed, num_beams, std_dev
@@ -91,15 +93,36 @@ def _np_ptr(a):
 
 
 class Engine(object):
+    NOISE_CHUNK = 256  # rows produced ahead of the cars at a time
+
     def __init__(self, num_envs=1, num_agents=1, params=None, seed=12345, fov=2 * np.pi, timestep=0.01,
                  integrator=1, ego_idx=0, num_beams=1080, eps=0.0001, theta_dis=2000, max_range=30.0,
-                 ttc_thresh=0.005, device=0, autoreset=False, noise_std=0.01, noise_steps=4096,
-                 keep_f64_scans=False, count_lookups=False):
+                 ttc_thresh=0.005, device=0, autoreset=False, noise_std=0.01, noise_steps=0,
+                 keep_f64_scans=False, count_lookups=False, noise_source='device'):
+        """`params`: one dict (every env, f110_env.py:125-128) or a sequence of num_envs dicts (env e constructed with
+        params[e]); `seed`: one int (:102-105) or a sequence of num_envs ints (at most F110_MAX_NOISE_SLOTS distinct).
+        `noise_source`: 'device' (rows produced on the GPU) or 'numpy' (NumPy draws on the host, rows uploaded);
+        `noise_steps`: rows to have ready at construction (0: the first step asks for them)."""
         if not torch.cuda.is_available():
             raise RuntimeError('red_gym_amd needs a HIP device (torch.cuda.is_available() is False); '
                                'there is no CPU path.')
+        if noise_source not in ('device', 'numpy'):
+            raise ValueError("noise_source must be 'device' or 'numpy'")
         self.lib = _lib.load()
+        env_params = None
+        if params is not None and not isinstance(params, dict):
+            env_params = [dict(p) for p in params]
+            if len(env_params) != int(num_envs):
+                raise ValueError('params must be one dict or a sequence of num_envs (%d) dicts' % int(num_envs))
+            params = env_params[0]
+        env_seeds = None
+        if not np.isscalar(seed) and seed is not None:
+            env_seeds = [int(x) for x in seed]
+            if len(env_seeds) != int(num_envs):
+                raise ValueError('seed must be one int or a sequence of num_envs (%d) ints' % int(num_envs))
+            seed = env_seeds[0]
         self.params = dict(DEFAULT_PARAMS if params is None else params)
+        self.autoreset = bool(autoreset)
         self.B, self.A, self.num_beams = int(num_envs), int(num_agents), int(num_beams)
         self.N = self.B * self.A
         self.fov, self.timestep, self.seed = float(fov), float(timestep), seed
@@ -124,13 +147,21 @@ class Engine(object):
                                             _np_ptr(self.side_distances)))
         self.map = None
         self.slot_shapes = {}
-        self.noise = None
-        self._noise_dev_rows = 0
         self.host_steps_bound = 0
-        if noise_std and noise_std > 0:
-            self.noise = NoiseTable(seed, self.num_beams, noise_std)
-            self._upload_noise(int(noise_steps))
+        self._steps_exact = False
+        self._noise_on = bool(noise_std and noise_std > 0)
+        self._noise_gen = self._noise_on and noise_source == 'device'
+        self._noise_rows, self._noise_floor, self._noise_prefetched = 0, 0, False
+        self._in_capture = False  # a stream capture is recording step(): no noise work (it was done in front of the capture)
+        self.noise_tables = []
+        if env_params is not None:
+            self.set_env_params(env_params)
+        if self._noise_on:
+            self._setup_noise(env_seeds if env_seeds is not None else [seed], float(noise_std))
         self._alloc(keep_f64_scans, count_lookups)
+        if self._noise_on and noise_steps:
+            with torch.cuda.device(self.device):
+                self._noise_to(int(noise_steps))
 
     # ------------------------------------------------------------------ buffers
     def _alloc(self, keep_f64, count_lookups):
@@ -159,22 +190,121 @@ class Engine(object):
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
-    def _upload_noise(self, rows):
-        tbl = self.noise.ensure(rows)
-        _lib.check(self.lib.f110_set_noise_table(self._h, _np_ptr(tbl), tbl.shape[0]))
-        self._noise_dev_rows = tbl.shape[0]
+    # ------------------------------------------------------------------ per-env constructor arguments
+    def set_env_params(self, env_params):
+        """env e drives the vehicle of env_params[e] (a sequence of num_envs dicts): what num_envs reference envs
+        constructed with their own `params` would do.  Equal dicts share a params slot."""
+        if len(env_params) != self.B:
+            raise ValueError('one params dict per env (%d), got %d' % (self.B, len(env_params)))
+        vecs = np.stack([params_vec(p) for p in env_params])
+        uniq, inv = np.unique(vecs, axis=0, return_inverse=True)
+        # slot 0 must be env 0's (the handle's constructor params: beam tables, defaults)
+        first = int(np.asarray(inv).reshape(-1)[0])
+        order = [first] + [k for k in range(uniq.shape[0]) if k != first]
+        remap = np.empty(uniq.shape[0], dtype=np.int32)
+        remap[order] = np.arange(uniq.shape[0], dtype=np.int32)
+        table = np.ascontiguousarray(uniq[order], dtype=np.float64)
+        assign = np.ascontiguousarray(remap[np.asarray(inv).reshape(-1)], dtype=np.int32)
+        _lib.check(self.lib.f110_set_params_slots(self._h, _np_ptr(table), table.shape[0]))
+        _lib.check(self.lib.f110_assign_params(self._h, _np_ptr(assign) if table.shape[0] > 1 else None))
+        self.env_params_assign = assign
 
-    def _grow_noise_if_needed(self):
-        """host_steps_bound counts steps since the last full reset: an upper bound of every
-        car's noise_step, kept on the host so that stepping never synchronises.  Only when the
-        bound reaches the table is the true maximum fetched (one tiny D2H copy per table-length
-        steps) and the table doubled if it is really needed."""
-        if self.noise is None or self.host_steps_bound + 1 < self._noise_dev_rows:
+    def _setup_noise(self, seeds, std):
+        """One noise slot per distinct seed (base_classes.py:117,202: all cars of an env draw from default_rng(seed))."""
+        uniq = []
+        for sd in seeds:
+            if sd not in uniq:
+                uniq.append(sd)
+        if len(uniq) > _lib.F110_MAX_NOISE_SLOTS:
+            raise ValueError('%d distinct seeds; a handle holds %d noise slots' % (len(uniq), _lib.F110_MAX_NOISE_SLOTS))
+        self.noise_seeds, self._noise_std = uniq, std
+        for k, sd in enumerate(uniq):
+            if self._noise_gen:
+                st = np.random.PCG64(sd).state['state']  # the stream np.random.default_rng(sd) starts from
+                m64 = (1 << 64) - 1
+                words = (C.c_uint64 * 4)(st['state'] & m64, st['state'] >> 64, st['inc'] & m64, st['inc'] >> 64)
+                _lib.check(self.lib.f110_set_noise_generator(self._h, k, words, std))
+            else:
+                self.noise_tables.append(NoiseTable(sd, self.num_beams, std))
+        if not self._noise_gen:
+            self._upload_host_noise(64)
+        if len(seeds) > 1:
+            assign = np.ascontiguousarray([uniq.index(sd) for sd in seeds], dtype=np.int32)
+            _lib.check(self.lib.f110_assign_noise(self._h, _np_ptr(assign) if len(uniq) > 1 else None))
+
+    def _upload_host_noise(self, rows):
+        for k, nt in enumerate(self.noise_tables):
+            tbl = nt.ensure(rows)
+            _lib.check(self.lib.f110_set_noise_slot(self._h, k, _np_ptr(tbl), tbl.shape[0]))
+        self._noise_rows = rows
+
+    def noise_info(self):
+        """(floor, rows produced, ring rows per slot, slots, bytes held) of the device noise table."""
+        lo, hi, cap, nbytes = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        slots = C.c_int32(0)
+        _lib.check(self.lib.f110_noise_info(self._h, C.byref(lo), C.byref(hi), C.byref(cap), C.byref(slots), C.byref(nbytes)))
+        return lo.value, hi.value, cap.value, slots.value, nbytes.value
+
+    def noise_rows(self, slot, row0, n_rows):
+        """Rows of the device noise table as a NumPy array [n_rows, num_beams] (tests / diagnostics; synchronises)."""
+        out = np.empty((int(n_rows), self.num_beams), dtype=np.float64)
+        _lib.check(self.lib.f110_noise_read(self._h, int(slot), int(row0), int(n_rows), _np_ptr(out)))
+        return out
+
+    def _noise_to(self, rows):
+        """Rows 0 .. rows-1 (above the floor) readable by the steps enqueued from now on."""
+        if self._noise_gen:
+            _lib.check(self.lib.f110_noise_ensure(self._h, int(rows), self._stream()))
+            self._noise_rows = self.noise_info()[1]  # (host-side bookkeeping of the library: no synchronisation)
+        elif rows > self._noise_rows:
+            self._upload_host_noise(max(int(rows), 2 * self._noise_rows))
+        self._noise_prefetched = False
+
+    def _set_noise_floor(self, lo):
+        if self._noise_gen and lo != self._noise_floor:
+            _lib.check(self.lib.f110_noise_set_floor(self._h, int(lo), self._stream()))
+            if lo < self._noise_floor:
+                self._noise_rows = 0  # the generators start over from their seeds
+            self._noise_floor = int(lo)
+
+    @on_own_device
+    def _ensure_noise(self, may_raise_floor=True):
+        """Keeps the noise table ahead of every car without synchronising: host_steps_bound counts steps since the last
+        full reset, an upper bound of every car's noise_step.  While the rows produced cover it, nothing happens (but the
+        next chunk is started on the library's side stream once half of the current one is used).  When the bound reaches
+        the table, the true (min, max) of the counters is fetched -- one small D2H copy per chunk of steps, none at all
+        when autoreset is off and no env was reset on its own, since every car then stands exactly at the bound -- when
+        the next chunk would not fit the table and cars cannot go back to row 0 by themselves (autoreset off), the floor
+        moves up to the slowest car instead of the table growing (a ring of constant size however long the run), and the
+        next chunk is produced.  may_raise_floor=False: a reset is about to send cars back to row 0."""
+        if not self._noise_on or self._in_capture:
             return
-        true_max = int(self.t['noise_step'].max().item())
-        if true_max + 2 >= self._noise_dev_rows:
-            self._upload_noise(2 * self._noise_dev_rows)
-        self.host_steps_bound = true_max
+        need = self.host_steps_bound + 2
+        if need <= self._noise_rows:
+            if self._noise_gen and not self._noise_prefetched and need + self.NOISE_CHUNK // 2 > self._noise_rows:
+                _lib.check(self.lib.f110_noise_prefetch(self._h, self._noise_rows + self.NOISE_CHUNK))
+                self._noise_prefetched = True
+            return
+        if self._steps_exact:
+            mn = mx = self.host_steps_bound
+        else:
+            mn, mx = (int(v) for v in torch.aminmax(self.t['noise_step']))
+            self.host_steps_bound = mx
+        target = mx + 2 + self.NOISE_CHUNK
+        if (self._noise_gen and may_raise_floor and not self.autoreset and mn > self._noise_floor
+                and target - self._noise_floor > self.noise_info()[2]):
+            self._set_noise_floor(mn)
+        if mx + 2 > self._noise_rows and self._noise_prefetched:
+            self._noise_to(mx + 2)   # the chunk that was produced beside the steps joins the table (a stream wait, no kernel)
+        if mx + 2 > self._noise_rows:
+            self._noise_to(target)   # not covered by a prefetch: produced now, in the caller's stream
+
+    def device_errors(self):
+        """The handle's device error word (f110_device_errors; synchronises): 0 = none, bit 0 = a car's noise row was
+        outside the table, bit 1 = an index check of the bounds-checked build failed."""
+        flags = C.c_uint32(0)
+        _lib.check(self.lib.f110_device_errors(self._h, C.byref(flags)))
+        return flags.value
 
     # ------------------------------------------------------------------ map / params
     def set_map(self, map_path, map_ext):
@@ -255,8 +385,13 @@ class Engine(object):
         poses = poses.to(device=self.device, dtype=torch.float64).contiguous()
         if mask is not None:
             mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
+            self._steps_exact = False      # some cars go back to row 0, the others run on
         else:
             self.host_steps_bound = 0
+            self._steps_exact = not self.autoreset
+        if self._noise_floor > 0:
+            self._set_noise_floor(0)       # cars at row 0 again: the rows below the floor are produced anew
+        self._ensure_noise(may_raise_floor=False)
         _lib.check(self.lib.f110_reset(self._h, _ptr(poses), _ptr(mask), self._stream()))
         self.host_steps_bound += 1
         self._keep = (poses, mask)  # keep inputs alive until the stream has consumed them
@@ -268,7 +403,7 @@ class Engine(object):
             raise ValueError('actions must have shape (%d, %d, 2)' % (self.B, self.A))
         if actions.dtype != torch.float64 or not actions.is_contiguous() or actions.device != self.device:
             actions = actions.to(device=self.device, dtype=torch.float64).contiguous()
-        self._grow_noise_if_needed()
+        self._ensure_noise()
         _lib.check(self.lib.f110_step(self._h, _ptr(actions), self._stream()))
         self.host_steps_bound += 1
         self._keep = actions

@@ -29,17 +29,21 @@ def resolve_map_path(map_name):
 class F110VecEnv(object):
     def __init__(self, num_envs, map=None, map_ext='.png', params=None, num_agents=2, timestep=0.01,
                  ego_idx=0, integrator=Integrator.RK4, fov=2 * np.pi, seed=12345, device=0, autoreset=True,
-                 num_beams=1080, noise_std=0.01, noise_steps=4096, keep_f64_scans=False, count_lookups=False,
-                 **_ignored):
+                 num_beams=1080, noise_std=0.01, noise_steps=0, keep_f64_scans=False, count_lookups=False,
+                 noise_source='device', **_ignored):
+        """The reference's constructor keywords (f110_env.py:100-157) plus the batch: `params` and `seed` may each be ONE
+        value for every env, or a sequence of num_envs values -- env e is then what `F110Env(params=params[e],
+        seed=seed[e])` would be (equal values share a slot on the device; at most 64 distinct seeds)."""
         self.num_envs, self.num_agents = int(num_envs), int(num_agents)
         self.map_name, self.map_ext = map, map_ext
         self.map_path = resolve_map_path(map)
-        self.params = dict(DEFAULT_PARAMS if params is None else params)
+        self.params = dict(DEFAULT_PARAMS if params is None else (params if isinstance(params, dict) else params[0]))
         self.timestep, self.ego_idx, self.seed = timestep, ego_idx, seed
-        self.eng = Engine(num_envs=num_envs, num_agents=num_agents, params=self.params, seed=seed, fov=fov,
+        self.eng = Engine(num_envs=num_envs, num_agents=num_agents, params=self.params if params is None or isinstance(params, dict) else params,
+                          seed=seed, fov=fov,
                           timestep=timestep, integrator=integrator, ego_idx=ego_idx, num_beams=num_beams,
                           device=device, autoreset=autoreset, noise_std=noise_std, noise_steps=noise_steps,
-                          keep_f64_scans=keep_f64_scans, count_lookups=count_lookups)
+                          keep_f64_scans=keep_f64_scans, count_lookups=count_lookups, noise_source=noise_source)
         self.eng.set_map(self.map_path, self.map_ext)
         self.device = self.eng.device
         t = self.eng.t
@@ -105,8 +109,11 @@ class F110VecEnv(object):
     def load_state_dict(self, sd):
         for k, v in sd.items():
             self.eng.t[k].copy_(v)
-        # the host's upper bound of any car's noise row must cover the restored counters
+        # the host's upper bound of any car's noise row must cover the restored counters, and the noise table their rows
         self.eng.host_steps_bound = max(self.eng.host_steps_bound, int(self.eng.t['noise_step'].max().item()) + 1)
+        self.eng._steps_exact = False
+        with torch.cuda.device(self.device):
+            self.eng._set_noise_floor(0)
 
     # ------------------------------------------------------------------ hipGraph replay
     def capture_step(self, policy=None, copies=1):
@@ -119,7 +126,7 @@ class F110VecEnv(object):
         if getattr(self, '_g_actions', None) is None:
             self._g_actions = torch.zeros((self.num_envs, self.num_agents, 2), dtype=torch.float64, device=self.device)
         self._g_policy = policy
-        self.eng._grow_noise_if_needed()
+        self.eng._ensure_noise()
         # `copies` > 1 captures that many identical graphs, replayed in turn (an experiment: two alternating execs
         # replay no faster than one, profiles/r02_graph_vs_eager.txt)
         if getattr(self, '_graphs', None):
@@ -131,11 +138,15 @@ class F110VecEnv(object):
             side = torch.cuda.Stream(device=self.device)
             side.wait_stream(torch.cuda.current_stream(self.device))
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.stream(side):
-                with torch.cuda.graph(g, stream=side):
-                    if policy is not None:
-                        policy(self, self._g_actions.view(-1, 2))
-                    self.eng.step(self._g_actions)
+            self.eng._in_capture = True
+            try:
+                with torch.cuda.stream(side):
+                    with torch.cuda.graph(g, stream=side):
+                        if policy is not None:
+                            policy(self, self._g_actions.view(-1, 2))
+                        self.eng.step(self._g_actions)
+            finally:
+                self.eng._in_capture = False
             torch.cuda.current_stream(self.device).wait_stream(side)
             self.eng.host_steps_bound -= 1  # the capture executed nothing: undo its host-side step accounting
             self._graphs.append(g)
@@ -152,7 +163,7 @@ class F110VecEnv(object):
         randomised) the step is re-captured first, so a replay never reads a freed table."""
         if actions is not None:
             self._g_actions.copy_(self._as_dev(actions, 2))
-        self.eng._grow_noise_if_needed()
+        self.eng._ensure_noise()
         if self.eng.launch_epoch() != self._g_epoch:
             self.capture_step(self._g_policy, self._g_copies)
         self._graphs[self._g_next].replay()
@@ -170,7 +181,7 @@ class F110VecEnv(object):
         if getattr(self, '_g_actions', None) is None:
             self._g_actions = torch.zeros((self.num_envs, self.num_agents, 2), dtype=torch.float64, device=self.device)
         self._drop_lib_graph()
-        self.eng._grow_noise_if_needed()
+        self.eng._ensure_noise()
         g = C.c_void_p()
         _lib.check(self.eng.lib.f110_graph_create(self.eng._h, C.c_void_p(self._g_actions.data_ptr()),
                                                   {'nodes': 0, 'capture': 1}[how], C.byref(g)))
@@ -194,7 +205,7 @@ class F110VecEnv(object):
         from . import _lib
         if actions is not None:
             self._g_actions.copy_(self._as_dev(actions, 2))
-        self.eng._grow_noise_if_needed()
+        self.eng._ensure_noise()
         if self.eng.launch_epoch() != self._lg_epoch:
             self.build_step_graph(self._lg_how)
         with torch.cuda.device(self.device):

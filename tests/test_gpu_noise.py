@@ -1,0 +1,222 @@
+"""The lidar noise on the GPU (csrc/f110_noise.h) and the per-env constructor arguments `seed` / `params`:
+rows produced on the device against NumPy's own `default_rng(seed).normal` (reference call site laser_models.py:450-452,
+seeding base_classes.py:117,202; golden g2 generated from the reference's rng use), K envs with K seeds and K vehicles
+in ONE handle against K separate oracle envs, the ring (flat memory in a long run), re-production after resets, and the
+device error word."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import oracle  # noqa: E402
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _scanner(assets):
+    sc = oracle.Scanner(1080, 2 * np.pi)
+    sc.set_map(os.path.join(assets, 'example_map.yaml'), '.png')
+    return sc
+
+
+def _engine(assets, **kw):
+    from red_gym_amd.engine import Engine
+    e = Engine(**kw)
+    e.set_map(os.path.join(assets, 'example_map.yaml'), '.png')
+    return e
+
+
+def test_device_rows_are_numpys_rows(assets, golden):
+    """Rows 0..1299 of six seeds `==` np.random.default_rng(seed).normal(0, 0.01, 1080) bit for bit outside the tail draws
+    and within one ulp of the tail value (|x| about 3.7..5, so 9e-16 x 0.01) there (the tail of the ziggurat calls log1p: device math library against glibc).
+    1 300 rows cross the first growth of the table (1 024 -> 2 048 rows per slot).  Seed 12345's first rows are also
+    the reference-generated golden g2."""
+    seeds = [12345, 0, 1, 7, 2 ** 31, 987654321987]
+    e = _engine(assets, num_envs=len(seeds), seed=seeds, noise_steps=1300)
+    g2 = golden('g2_noise.npz')['seed12345']
+    n_tail = n_diff = 0
+    for k, sd in enumerate(seeds):
+        got = e.noise_rows(k, 0, 1300)
+        rng = np.random.default_rng(sd)
+        ref = np.stack([rng.normal(0., 0.01, size=1080) for _ in range(1300)])
+        tail = np.abs(ref) > 0.01 * 3.6541528853610088          # |x| > ziggurat_nor_r: produced by the log1p branch
+        assert np.array_equal(got[~tail], ref[~tail]), sd
+        assert np.allclose(got[tail], ref[tail], rtol=0, atol=2e-17), sd
+        n_tail += int(tail.sum()); n_diff += int((got != ref).sum())
+        if sd == 12345:
+            assert np.array_equal(got[:g2.shape[0]][~tail[:g2.shape[0]]], g2[~tail[:g2.shape[0]]])
+    assert n_tail > 500                                          # 0.026 % of 8.4 M draws
+    print('tail draws: %d, of which not bit-identical to glibc: %d' % (n_tail, n_diff))
+    assert e.device_errors() == 0
+    e.close()
+
+
+@pytest.mark.parametrize('source', ['device', 'numpy'])
+def test_k_seeds_and_k_vehicles_are_k_reference_envs(assets, source):
+    """One handle, 12 envs built with 4 seeds x 3 `params` dicts (f110_env.py:102-105,125-128), two agents, autoreset:
+    every env `==` its own oracle Env constructed with that seed's noise rows and that params dict, 60 steps through
+    wall hits and resets (state / scans 1e-9, collisions, toggles, done ==)."""
+    import torch
+    from red_gym_amd import F110VecEnv, workload
+    from red_gym_amd.engine import DEFAULT_PARAMS
+    B, A, T = 12, 2, 60
+    seeds = [11, 22, 33, 44]
+    pvar = [dict(DEFAULT_PARAMS), dict(DEFAULT_PARAMS, mu=0.7, C_Sf=3.9, m=4.5, a_max=7.0), dict(DEFAULT_PARAMS, mu=1.3, lf=0.17, lr=0.16, I=0.05, sv_max=2.5, width=0.29, length=0.55)]
+    env_seed = [seeds[e % 4] for e in range(B)]
+    env_par = [pvar[e % 3] for e in range(B)]
+    env = F110VecEnv(B, map=os.path.join(assets, 'example_map'), num_agents=A, seed=env_seed, params=env_par, autoreset=True,
+                     keep_f64_scans=True, noise_source=source)
+    sc = _scanner(assets)       # beam tables: the first env's params (class-level statics of the reference, base_classes.py:116-156)
+    tables = {sd: oracle.noise_table(sd, T + 4) for sd in seeds}
+    ors = [oracle.Env(sc, A, params=env_par[e], noise=tables[env_seed[e]]) for e in range(B)]
+    poses = workload.spawn_poses(B, A)
+    acts = workload.action_pool(8, B, A)
+    acts[:, 3:7, :, 0] = 0.35
+    acts[:, 3:7, :, 1] = 7.0     # some envs steer into the wall: iTTC hit, done, autoreset
+    env.reset(poses)
+    oo = [ors[e].reset(poses[e]) for e in range(B)]
+    pend = np.zeros(B, dtype=bool)
+    dones = 0
+    for k in range(T):
+        obs, _, done, info = env.step(torch.as_tensor(acts[k % 8], device='cuda'))
+        for e in range(B):
+            oo[e] = ors[e].reset(poses[e]) if pend[e] else ors[e].step(acts[k % 8][e])
+        st, sc64 = _np(env.state), _np(obs['scans_f64'])
+        for e in range(B):
+            assert np.allclose(st[e], oo[e]['state'], rtol=0, atol=1e-9), (k, e)
+            assert np.allclose(sc64[e], oo[e]['scans'], rtol=0, atol=1e-9), (k, e)
+            assert np.array_equal(_np(obs['collisions'])[e].astype(np.float64), oo[e]['collisions']), (k, e)
+            assert np.array_equal(_np(info['toggles'])[e].astype(np.float64), oo[e]['toggles']), (k, e)
+            assert bool(_np(done)[e]) == oo[e]['done'], (k, e)
+        pend = _np(done).astype(bool)
+        dones += int(pend.sum())
+    assert dones > 0
+    # different seeds really are different streams, different vehicles different trajectories
+    assert not np.array_equal(sc64[0], sc64[1]) and env.eng.device_errors() == 0
+    env.close()
+
+
+def test_update_params_reaches_every_slot_and_one_slot_only(assets):
+    """f110_update_params (Simulator.update_params, base_classes.py:507-527) applies to the agent in EVERY env;
+    f110_set_params_slot(slot, agent) to that env's agent only; IndexError beyond the agent list."""
+    import torch
+    from red_gym_amd import F110VecEnv, _lib, workload
+    from red_gym_amd.engine import DEFAULT_PARAMS, params_vec
+    B, A = 4, 2
+    pa, pb, pc = dict(DEFAULT_PARAMS), dict(DEFAULT_PARAMS, mu=0.6), dict(DEFAULT_PARAMS, mu=1.4, a_max=5.0)
+    env = F110VecEnv(B, map=os.path.join(assets, 'example_map'), num_agents=A, params=[pa, pb, pa, pb], autoreset=False,
+                     keep_f64_scans=True, noise_std=0)
+    env.update_params(pc, index=1)                                     # agent 1 of every env
+    v = params_vec(pb); v[0] = 0.9                                     # agent 0 of the envs on slot 1 only
+    _lib.check(env.eng.lib.f110_set_params_slot(env.eng._h, 1, v.ctypes.data_as(C.c_void_p), 0))
+    with pytest.raises(IndexError):
+        env.update_params(pc, index=2)
+    sc = _scanner(assets)
+    poses = workload.spawn_poses(B, A)
+    acts = workload.action_pool(8, B, A)
+    env.reset(poses)
+    # the oracle's Env holds ONE params vector for all its agents: drive each agent in an env of its own kind
+    p_agent = lambda e, a: pc if a == 1 else (dict(pb, mu=0.9) if e % 2 == 1 else pa)  # noqa: E731
+    solo = [[oracle.Env(sc, 1, params=p_agent(e, a)) for a in range(A)] for e in range(B)]
+    for e in range(B):
+        for a in range(A):
+            solo[e][a].reset(poses[e, a:a + 1])
+    for k in range(25):
+        env.step(torch.as_tensor(acts[k % 8], device='cuda'))
+        st = _np(env.state)
+        for e in range(B):
+            for a in range(A):
+                assert np.allclose(st[e, a], solo[e][a].step(acts[k % 8][e, a:a + 1])['state'][0], rtol=0, atol=1e-9), (k, e, a)
+    env.close()
+
+
+def test_long_run_is_a_ring_of_constant_size(assets):
+    """20 000 steps, autoreset off, replayed from ONE captured hipGraph: the noise table stays at its first size (a ring
+    following the cars), the launch epoch never moves (no re-capture), no device error, and the scans are NumPy's rows.
+    The cars sit inside a wall (the first table read is 0: every beam returns 0 + noise), so a scan IS its noise row."""
+    import torch
+    from red_gym_amd import F110VecEnv
+    B, T = 4, 20000
+    seeds = [5, 6, 5, 6]
+    env = F110VecEnv(B, map=os.path.join(assets, 'example_map'), num_agents=1, seed=seeds, autoreset=False, keep_f64_scans=True)
+    poses = np.tile(np.array([[[-45.87478769831466, -16.282154624538293, 0.3]]]), (B, 1, 1))   # the centre of a wall cell (map row 449, col 517)
+    env.reset(poses)
+    buf = env.capture_step()
+    buf.zero_()
+    ep0, bytes0 = env.eng.launch_epoch(), env.eng.noise_info()[4]
+    rows = {sd: np.random.default_rng(sd) for sd in (5, 6)}
+    ref = {sd: rows[sd].normal(0., 0.01, size=1080) for sd in (5, 6)}  # row 0 went to the reset's scan
+    check_at = set(range(0, T, 997)) | {1023, 1024, 1025, 2047, 2048, T - 1}
+    for k in range(T):
+        env.step_graph()
+        ref = {sd: rows[sd].normal(0., 0.01, size=1080) for sd in (5, 6)}
+        if k in check_at:
+            s = _np(env.eng.t['scans_f64'])
+            for e in range(B):
+                r = ref[seeds[e]]
+                tail = np.abs(r) > 0.01 * 3.6541528853610088
+                assert np.array_equal(s[e, 0][~tail], r[~tail]), (k, e)
+                assert np.allclose(s[e, 0], r, rtol=0, atol=2e-17), (k, e)
+    lo, hi, cap, slots, nbytes = env.eng.noise_info()
+    assert env.eng.launch_epoch() == ep0 and nbytes == bytes0 and cap == 1024 and slots == 2
+    assert lo > T - 1024 - 300 and hi > T and env.eng.device_errors() == 0
+    assert int(env.eng.t['noise_step'].min()) == T + 1
+    # a masked reset sends two cars back to row 0 while the others run on: the dropped rows are produced again
+    m = torch.zeros(B, dtype=torch.uint8, device='cuda'); m[:2] = 1
+    env.reset(poses, m)
+    rr = {sd: np.random.default_rng(sd) for sd in (5, 6)}
+    first = {sd: rr[sd].normal(0., 0.01, size=1080) for sd in (5, 6)}
+    s = _np(env.eng.t['scans_f64'])
+    for e in (0, 1):
+        assert np.allclose(s[e, 0], first[seeds[e]], rtol=0, atol=2e-17), e
+    env.step(torch.zeros((B, 1, 2), dtype=torch.float64, device='cuda'))
+    s = _np(env.eng.t['scans_f64'])
+    nxt = {sd: rows[sd].normal(0., 0.01, size=1080) for sd in (5, 6)}
+    sec = {sd: rr[sd].normal(0., 0.01, size=1080) for sd in (5, 6)}
+    for e in range(B):
+        assert np.allclose(s[e, 0], (sec if e < 2 else nxt)[seeds[e]], rtol=0, atol=2e-17), e
+    assert env.eng.device_errors() == 0 and env.eng.noise_info()[2] >= 32768   # the ring now spans rows 0 .. 20 002
+    env.close()
+
+
+def test_autoreset_keeps_every_row_and_grows_quietly(assets):
+    """autoreset on: a car may be sent back to row 0 at any step, so rows are never dropped; a car that outlives the table
+    makes it double (1 024 -> 2 048) without moving the launch epoch, and a captured graph keeps replaying."""
+    import torch
+    from red_gym_amd import F110VecEnv
+    B = 2
+    e1 = F110VecEnv(B, map=os.path.join(assets, 'example_map'), num_agents=1, autoreset=True, keep_f64_scans=True)
+    e2 = F110VecEnv(B, map=os.path.join(assets, 'example_map'), num_agents=1, autoreset=True, keep_f64_scans=True, noise_source='numpy')
+    poses = np.array([[[0.7, 0.0, 1.37079632679]], [[0.0, 20.0, 0.3]]])
+    e1.reset(poses); e2.reset(poses)
+    buf = e1.capture_step()
+    buf.zero_()
+    ep0 = e1.eng.launch_epoch()
+    z = torch.zeros((B, 1, 2), dtype=torch.float64, device='cuda')
+    for k in range(1100):
+        e1.step_graph(); e2.step(z)
+        if k % 100 == 99 or k > 1015:
+            assert torch.allclose(e1.eng.t['scans_f64'], e2.eng.t['scans_f64'], rtol=0, atol=2e-17), k
+    assert e1.eng.launch_epoch() == ep0 and e1.eng.noise_info()[0] == 0 and e1.eng.noise_info()[2] == 2048
+    assert e1.eng.device_errors() == 0 and e2.eng.device_errors() == 0
+    e1.close(); e2.close()
+
+
+def test_a_row_outside_the_table_is_reported(assets):
+    """The raw ABI stepped past the rows it was told to produce: F110_DEVERR_NOISE_WINDOW in the device error word."""
+    import torch
+    e = _engine(assets, num_envs=2, noise_steps=64)
+    poses = torch.as_tensor(np.array([[[0.7, 0.0, 1.37]], [[0.7, 0.0, 1.37]]]), device='cuda')
+    e.reset(poses)
+    assert e.device_errors() == 0
+    e.t['noise_step'].fill_(5000)           # as if the cars had made 5 000 scans nobody announced
+    a = torch.zeros((2, 1, 2), dtype=torch.float64, device='cuda')
+    with torch.cuda.device(e.device):
+        assert e.lib.f110_step(e._h, C.c_void_p(a.data_ptr()), None) == 0
+    assert e.device_errors() == 1 and e.device_errors() == 0      # reported once, then cleared
+    e.close()

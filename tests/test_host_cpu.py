@@ -41,6 +41,25 @@ def test_noise_table_is_numpy_stream(golden):
     assert np.array_equal(NoiseTable(12345, 1080).ensure(2), rows[:2]) and not np.array_equal(rows[0], rows[1])
 
 
+def test_ziggurat_tables_and_the_generator_model(golden):
+    """The device noise generator (csrc/f110_noise.h) is compiled with csrc/f110_ziggurat.h.  Its CPU model --
+    tools/make_ziggurat_tables.py: PCG64 + ziggurat restated with those committed tables -- reproduces the golden rows the
+    reference's rng use produced (g2) and NumPy's stream for other seeds, wedge and tail branches included."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    import make_ziggurat_tables as z
+    tables = z.read_header()
+    assert len(tables[0]) == len(tables[1]) == len(tables[2]) == 256 and tables[2][0] == 1.0
+    g = golden('g2_noise.npz')['seed12345']
+    assert np.array_equal(z.emulate_rows(12345, 3, 1080, 0.01, tables), g[:3])
+    stats = {}
+    for seed in (0, 7, 2 ** 40 + 3):
+        rng = np.random.default_rng(seed)
+        ref = np.stack([rng.normal(0., 0.01, size=1080) for _ in range(2)])
+        assert np.array_equal(z.emulate_rows(seed, 2, 1080, 0.01, tables, stats), ref), seed
+    assert stats.get('wedge', 0) > 10
+
+
 def test_beam_tables_match_reference(golden):
     from red_gym_amd.engine import DEFAULT_PARAMS, beam_tables
     g = golden('g5_ttc.npz')
