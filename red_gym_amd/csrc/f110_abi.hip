@@ -75,7 +75,7 @@ struct f110_handle {
     int d_params_slots = 0;           // slots the device allocation holds
     int32_t *d_env_params = nullptr;  // dev [B] params slot of every env; passed to the kernels only when `multi_params`
     bool multi_params = false;
-    OppPair *d_opp_pairs = nullptr;   // [N, A-1] opponent ray-cast scratch
+    OppPair *d_opp_pairs = nullptr;   // [N, A-1] opponent ray-cast scratch (never allocated in f110_step)
     bool has_map = false, bound = false;
     // Bumped whenever a later f110_step would enqueue different kernels or by-value arguments than an earlier one
     // (a table re-allocated, another scan instantiation selected, buffers re-bound): f110_launch_epoch.
@@ -306,6 +306,7 @@ static int alloc_opp_pairs(f110_handle *h)
     if (h->cfg.num_agents < 2) return F110_OK;
     const size_t n = (size_t)h->cfg.num_envs * h->cfg.num_agents * (h->cfg.num_agents - 1);
     HIP_TRY(hipMalloc((void **)&h->d_opp_pairs, n * sizeof(OppPair)));
+    HIP_TRY(hipMemset(h->d_opp_pairs, 0, n * sizeof(OppPair)));
     return F110_OK;
 }
 
@@ -1261,6 +1262,8 @@ static int emit(const Sink &k, const void *func, dim3 grid, dim3 block, unsigned
     return F110_OK;
 }
 
+static Sink make_sink(f110_handle *h, hipStream_t st, std::vector<KernelLaunch> *record = nullptr);
+
 static ScanDev scan_dev(const f110_handle *h)
 {
     ScanDev s;
@@ -1510,13 +1513,14 @@ static int run_step(f110_handle *h, const double *actions, int reset_only, const
 
     if (c.num_agents > 1) {
         OppArgs o;
+        memset(&o, 0, sizeof(o));
         o.n_cars = N; o.agents = c.num_agents; o.nb = c.num_beams; o.state = b.state; o.pose_snap = b.pose_snap;
         o.in_collision = b.in_collision; o.scan_angles = h->d_scan_angles; o.beam_cs = h->d_beam_cs; o.params = h->d_params; o.env_params = h->multi_params ? h->d_env_params : nullptr;
         o.pending_reset = b.pending_reset; o.reset_only = reset_only; o.scans32 = b.scans; o.scans64 = b.scans_f64;
         o.pairs = h->d_opp_pairs;
         const int npairs = N * (c.num_agents - 1);
-        if ((rc = emit(st, (const void *)&opp_setup_kernel, dim3((npairs + 127) / 128), dim3(128), 0, o))) return rc;
-        if ((rc = emit(st, (const void *)&opp_apply_kernel, dim3((N + 3) / 4), dim3(256), 0, o))) return rc;
+        if ((rc = emit(st, (const void *)&opp_setup_kernel, dim3((4 * npairs + 127) / 128), dim3(128), 0, o))) return rc; // four lanes per pair
+        if ((rc = emit(st, (const void *)&opp_apply_kernel, dim3((int)(((long long)OPP_GROUP * N + 255) / 256)), dim3(256), 0, o))) return rc; // OPP_GROUP lanes per car
     }
 
     EnvArgs e;
@@ -1527,6 +1531,14 @@ static int run_step(f110_handle *h, const double *actions, int reset_only, const
     e.lap_times = b.lap_times; e.current_time = b.current_time; e.pending_reset = b.pending_reset; e.done = b.done; e.checkpoint_done = b.checkpoint_done;
     e.time_step = c.timestep; e.params = h->d_params; e.env_params = h->multi_params ? h->d_env_params : nullptr;
     return emit(st, (const void *)&env_kernel, dim3((c.num_envs + 127) / 128), dim3(128), 0, e);
+}
+
+static Sink make_sink(f110_handle *h, hipStream_t st, std::vector<KernelLaunch> *record)
+{
+    Sink k;
+    (void)h;
+    k.st = st; k.record = record;
+    return k;
 }
 
 static int check_ready(f110_handle *h, const char *who, bool launches_on_callers_stream = true)
@@ -1560,9 +1572,7 @@ extern "C" int f110_reset(f110_handle *h, const double *poses, const uint8_t *ma
                        c.num_agents, h->bufs.spawn, h->bufs.pending_reset);
     HIP_TRY(hipGetLastError());
     // the zero-action step of F110Env.reset; actions are not read for pending envs
-    Sink k;
-    k.st = st;
-    return run_step(h, nullptr, 1, k);
+    return run_step(h, nullptr, 1, make_sink(h, st));
 }
 
 extern "C" int f110_step(f110_handle *h, const double *actions, void *stream)
@@ -1570,9 +1580,7 @@ extern "C" int f110_step(f110_handle *h, const double *actions, void *stream)
     int rc = check_ready(h, "f110_step");
     if (rc) return rc;
     if (!actions) return fail(F110_E_INVALID, "f110_step: null actions");
-    Sink k;
-    k.st = (hipStream_t)stream;
-    return run_step(h, actions, 0, k);
+    return run_step(h, actions, 0, make_sink(h, (hipStream_t)stream));
 }
 
 // ---------------------------------------------------------------- the step as a HIP graph built by the library
@@ -1610,9 +1618,7 @@ extern "C" int f110_graph_create(f110_handle *h, const double *actions, int32_t 
     h->prof_on = false; // events cannot ride on graph nodes
     hipError_t e = hipSuccess;
     if (how == F110_GRAPH_NODES) {
-        Sink k;
-        k.record = &g->launches;
-        rc = run_step(h, actions, 0, k);
+        rc = run_step(h, actions, 0, make_sink(h, nullptr, &g->launches));
         if (!rc) {
             e = hipGraphCreate(&g->graph, 0);
             hipGraphNode_t prev = nullptr;
@@ -1633,9 +1639,7 @@ extern "C" int f110_graph_create(f110_handle *h, const double *actions, int32_t 
         e = hipStreamCreateWithFlags(&g->cap, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipStreamBeginCapture(g->cap, hipStreamCaptureModeThreadLocal);
         if (e == hipSuccess) {
-            Sink k;
-            k.st = g->cap;
-            rc = run_step(h, actions, 0, k);
+            rc = run_step(h, actions, 0, make_sink(h, g->cap));
             e = hipStreamEndCapture(g->cap, &g->graph);
             size_t n = 0;
             if (e == hipSuccess && hipGraphGetNodes(g->graph, nullptr, &n) == hipSuccess) g->nodes = (int)n;

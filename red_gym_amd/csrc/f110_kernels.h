@@ -1,8 +1,8 @@
 // f110_kernels.h -- the kernels of one batched env step on gfx950, in launch order:
 //   dynamics_kernel   (lane per car)        RaceCar.update_pose minus the scan (+ reset)
 //   scan_kernel       (wave per car)        ScanSimulator2D.scan + noise + iTTC
-//   opp_setup_kernel  (lane per car pair)   \ RaceCar.ray_cast_agents, only when A > 1
-//   opp_apply_kernel  (wave per car)        /
+//   opp_setup_kernel  (4 lanes per car pair) \ RaceCar.ray_cast_agents, only when A > 1
+//   opp_apply_kernel  (wave per car)         /
 //   env_kernel        (lane per env)        GJK, collision flags, iTTC state update, lap timing, done, autoreset
 // plus small function-level kernels used by the parity entry points.
 #pragma once
@@ -477,24 +477,28 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
 }
 
 // ------------------------------------------------------------------ opponents (A > 1)
-// RaceCar.ray_cast_agents (base_classes.py:204-225): the car's CURRENT pose (yaw already
-// zeroed by an iTTC hit, :245) against the other cars' post-integration snapshot poses.
-// Two kernels: a set-up with all the fp64 trigonometry (one lane per (car, opponent) pair:
-// opponent corners, blocked beam span, beam-direction rotation) and a lean apply kernel
-// (one lane per (car, beam)) that tests the four edges for the beams inside a span.  A
-// single wave-per-car kernel with the trig inlined needed 162 VGPRs and was latency-bound
-// at 2 waves/SIMD (0.165 ms at 32 768 cars); kept out of scan_kernel in any case so the
-// march loop stays at 45 VGPRs.
-struct OppPair {
-    double px, py, cA, sA; // ego position, cos/sin(yaw + pi/2)
-    double v[8];           // opponent corners rl, rr, fr, fl
-    double qx, qy, reach;  // opponent centre relative to the ego, padded half diagonal: a ray whose line passes
-                           // the centre at more than `reach` cannot cross an edge (conservative pre-test, see opp_apply)
-    int lo, hi;            // get_blocked_view_indices span (lo > hi: nothing to do)
-    unsigned long long chunks; // bit c: the 64-beam chunk c of [lo, hi] holds beams whose LINE passes the opponent's bounding
-                               // circle (a chunk-granular form of opp_apply's per-beam pre-test: the other chunks are skipped)
-};
-
+// RaceCar.ray_cast_agents (base_classes.py:204-225) -> ray_cast (laser_models.py:319-346): the car's CURRENT pose (yaw
+// already zeroed by an iTTC hit, :245) against the other cars' post-integration snapshot poses.
+// Two kernels behind the scan:
+//   opp_setup_kernel, FOUR LANES PER (car, opponent) PAIR (lane c = corner c = edge c of the opponent's quad): every lane
+//     takes one corner through the arctan2 / arg-min of get_blocked_view_indices (:283-315) and one edge through what
+//     get_range (:250-280) computes from the pose and two corners alone; span, angular hull and the beam intervals worth
+//     visiting come from quad-wide min / max;
+//   opp_apply_kernel, a group of OPP_GROUP lanes per car (a whole wave as built): the pair is staged in LDS by vector loads
+//     (no chain of dependent scalar loads at the head of the wave) and the lanes share the beams of the intervals.  Per
+//     beam the front-facing edges are tested with get_range's own conditions (:271-274), decided without dividing; the
+//     nearest hit is min over the passing edges of fl(cross / denom), and because rounding is monotonic that is fl() of
+//     the EXACT smallest quotient: the edges are compared as exact fractions (frac_less), one division per beam.
+// The kernel's time is instruction issue (PMC: one wave-iteration costs the chip what its VALU can issue), so what counts
+// is instructions per beam and idle lanes: groups of 8 / 16 / 32 / 64 lanes take 52 / 33 / 27 / 23 us at 32 768 cars (a
+// wave waits for its slowest group), and four lanes per car for set-up AND ray cast in one kernel 67 us.  History: one wave-per-car kernel
+// with the trig inlined 0.165 ms at 32 768 cars (162 VGPRs) -> set-up / apply split 108 us -> wave per car 86 ->
+// conservative pre-test 50 -> chunk masks 44 + 17 us (round 3) -> round 4: intervals from the corners' angular hull,
+// per-edge constants, one division per beam, four lanes per pair in the set-up: 39 + 11 us -> front-facing edges only,
+// the pair in LDS: 23 + 13 us (profiles/r04_opponents.txt).  Round 4 also measured two other placements, both exact, both slower: the ray
+// cast INSIDE scan_kernel at the end of the wave that marched the car (+37 us on the scan: a wave that lingers for a chain
+// of dependent loads keeps its slot from a marching one), and the set-up on a side stream beside the scan (the fork /
+// join event waits cost the stream more than the set-up takes).
 struct OppArgs {
     int n_cars, agents, nb;
     const double *state;      // [N,7]
@@ -506,142 +510,297 @@ struct OppArgs {
     const int32_t *env_params;// [B] or NULL
     const uint8_t *pending_reset;
     int reset_only;
-    OppPair *pairs;           // [N, agents-1] scratch owned by the handle
+    struct OppPair *pairs;    // [N, agents-1] scratch owned by the handle
     float *scans32;           // [N,nb] or NULL
     double *scans64;          // [N,nb] or NULL
 };
 
+// exact "n1 / d1 < n2 / d2" for non-negative numerators and positive denominators: the rounded products decide unless
+// they are equal, then the exact residuals of the two products do (fma).  No overflow / underflow for physical ranges.
+__device__ inline bool frac_less(double n1, double d1, double n2, double d2)
+{
+    const double p1 = n1 * d2, p2 = n2 * d1;
+    if (p1 != p2) return p1 < p2;
+    return __builtin_fma(n1, d2, -p1) < __builtin_fma(n2, d1, -p2);
+}
+
+// One beam of the ray cast against one opponent: get_range over the four edges (see the section comment), then the
+// in-place minimum (laser_models.py:343-344) on the fp64 and / or fp32 scan.
+struct OppPairRegs {
+    double px, py, cA, sA, qx, qy, reach;         // ego position; cos / sin(yaw + pi/2); opponent centre relative to the ego and
+                                                  // its padded half diagonal (conservative pre-test, opp_test_beam)
+    // Per edge: o - va (:258), vb - va (:259), cross(v2, v1) (:267), and its end points va, vb (collinear branch only).
+    // The edges are stored FRONT-FACING FIRST (n_front of them: the car lies on their outer side).  A ray from outside a
+    // convex quad enters through a front-facing edge, and the point where it leaves through a back-facing one is never
+    // nearer, so min over the passing edges (:336-341) is decided by the front-facing ones; the others only keep their
+    // test for the collinear branch (denom == 0, :275-280), which answers whatever the facing.  With the car INSIDE the
+    // quad (overlapping cars) no edge faces it: n_front = 4, every edge takes the full test.
+    double v1x[4], v1y[4], v2x[4], v2y[4], cr[4];
+    double ax[4], ay[4], bx[4], by[4];
+    int n_front, pad;
+};
+constexpr int OPP_MAX_IV = 3;
+// what opp_setup_kernel leaves for opp_apply_kernel
+struct OppPair {
+    OppPairRegs r;
+    // Disjoint, ascending beam intervals [iv[2k], iv[2k+1]] inside the reference's span [lo, hi] that hold every beam
+    // get_range can answer for: a finite range needs the ray to point AT the quad, i.e. its angle inside the angular hull
+    // of the four corners as seen from the car (or, for the collinear branch :275-280, exactly away from it: hull + pi).
+    // Normally the hull IS [lo, hi].  With the opponent behind the car the corner angles straddle +-pi and the
+    // reference's span becomes nearly the whole scan (:293-315) although only the few beams at its two ends -- and, for
+    // the collinear branch, the beams pointing straight ahead -- lie in the hull: three short intervals instead of
+    // ~1 000 beams.  Conservative (two beams of margin), so the beams that can be modified are all inside and the
+    // results are the per-beam tests'.
+    int n_iv, total, iv[2 * OPP_MAX_IV]; // total = beams in the intervals (0: nothing to do)
+};
+
+__device__ inline void opp_test_beam(const OppPairRegs *o, const double2 *__restrict__ beam_cs, int i, float *s32, double *s64)
+{
+    // (*o lives in LDS: its fields are read where they are used, edge by edge, so that few of them are live at a time and
+    // the kernel keeps 8 waves per SIMD -- its time is memory latency, which only more waves hide)
+    const double2 cs = beam_cs[i];
+    const double cA = o->cA, sA = o->sA;
+    const double v3x = cA * cs.x - sA * cs.y, v3y = sA * cs.x + cA * cs.y;
+    // v3 is the ray's unit normal (laser_models.py:262): |q . v3| is the distance of the opponent's centre
+    // from the ray's line.  Beyond the padded half diagonal no edge can be crossed (every get_range would return inf).
+    const double qx = o->qx, qy = o->qy, reach = o->reach;
+    if (!(fabs(qx * v3x + qy * v3y) <= reach)) return;
+    // The ray's direction is (v3y, -v3x).  If the whole bounding circle lies BEHIND the car along it, every edge
+    // point has a negative ray parameter: get_range rejects it (d1 >= 0, :271) -- unless an edge is exactly
+    // parallel to the ray (denom == 0: the collinear branch answers whatever the direction, :275-280).
+    const bool behind = qx * v3y - qy * v3x < -reach;
+    bool has = false;
+    double bn = 0.0, bd = 1.0;          // the nearest hit so far as a fraction cross / denom (signed, as get_range divides them)
+    double direct = __builtin_inf();    // distances the collinear branch produced
+    const int n_front = o->n_front;
+#pragma unroll 1
+    for (int e = 0; e < 4; e++) {
+        const double denom = o->v2x[e] * v3x + o->v2y[e] * v3y;          // :266
+        if (fabs(denom) > 0.0) {
+            if (behind || e >= n_front) continue;
+            // d1 = cross / denom >= 0, 0 <= d2 = dot / denom <= 1 (:271-274) decided without dividing:
+            // the sign of an IEEE quotient is the sign product, and fl(q) <= 1 <=> q <= 1.
+            const double cr = o->cr[e];
+            const double dt = o->v1x[e] * v3x + o->v1y[e] * v3y;       // :268
+            const bool dpos = denom > 0.0;
+            const bool d1_ok = (cr == 0.0) || ((cr > 0.0) == dpos);
+            const bool d2_ge0 = (dt == 0.0) || ((dt > 0.0) == dpos);
+            const bool d2_le1 = dpos ? (dt <= denom) : (dt >= denom);
+            if (d1_ok && d2_ge0 && d2_le1) {
+                if (!has || frac_less(fabs(cr), fabs(denom), fabs(bn), fabs(bd))) { bn = cr; bd = denom; }
+                has = true;
+            }
+        } else {
+            // are_collinear(o, va, vb) :233-247, then the nearer corner (:278-280)
+            const double px = o->px, py = o->py;
+            const double bax = o->ax[e] - px, bay = o->ay[e] - py;
+            const double cax = px - o->bx[e], cay = py - o->by[e];
+            if (fabs(bax * cay - bay * cax) < 1e-8) {
+                const double ebx = o->bx[e] - px, eby = o->by[e] - py;
+                const double da = sqrt(bax * bax + bay * bay), db = sqrt(ebx * ebx + eby * eby);
+                const double d = da < db ? da : db;
+                if (d < direct) direct = d;
+            }
+        }
+    }
+    double best = direct;
+    if (has) { const double q = bn / bd; if (q < best) best = q; }   // :273 distance = d1
+    if (best < __builtin_inf()) {
+        if (s64) { double *s = s64 + i; if (best < *s) *s = best; }
+        if (s32) { float *s = s32 + i; const float b32 = (float)best; if (b32 < *s) *s = b32; }
+    }
+}
+
+// beam number tt of the intervals taken as one index space (-1: past the end)
+__device__ inline int opp_iv_beam(const int *iv, int n_iv, int tt)
+{
+    int i = -1, rem = tt;
+#pragma unroll
+    for (int k = 0; k < OPP_MAX_IV; k++)
+        if (k < n_iv) {
+            const int len = iv[2 * k + 1] - iv[2 * k] + 1;
+            if (i < 0 && rem < len) i = iv[2 * k] + rem;
+            rem -= len;
+        }
+    return i;
+}
+
+// Four lanes per (car, opponent) pair.
 __global__ __launch_bounds__(128) void opp_setup_kernel(OppArgs a)
 {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int p = t >> 2, c = t & 3;
     const int per = a.agents - 1;
-    if (p >= a.n_cars * per) return;
+    if (p >= a.n_cars * per) return; // (whole quads leave together)
     const int car = p / per, jj = p % per;
     const int env = car / a.agents, a0 = env * a.agents, self = car - a0;
-    OppPair &o = a.pairs[p];
-    if (a.reset_only && !a.pending_reset[env]) { o.lo = 1; o.hi = 0; o.chunks = 0ull; return; }
+    OppPair &out = a.pairs[p];
+    if (a.reset_only && !a.pending_reset[env]) { if (c == 0) { out.n_iv = 0; out.total = 0; } return; }
     const int j = jj < self ? jj : jj + 1; // opponents in agent order, skipping the car itself (:574)
     const double *st = a.state + (size_t)car * 7;
-    // an iTTC hit zeroes the yaw before the ray cast (base_classes.py:245); env_kernel applies it
+    // an iTTC hit zeroes the yaw before the ray cast (base_classes.py:245); env_kernel writes the zero into the state later
     const double px = st[0], py = st[1], pyaw = a.in_collision[car] ? 0.0 : st[4];
     const double *op = a.pose_snap + (size_t)(a0 + j) * 3;
     const Params &P = a.params[(size_t)(a.env_params ? a.env_params[env] : 0) * (a.agents + 1) + 1 + self];
     double verts[4][2];
     get_vertices(op[0], op[1], op[2], P.v[P_LENGTH], P.v[P_WIDTH], verts);
+    const int cn = (c + 1) & 3;
+    double cx, cy, nx, ny; // this lane's corner and the next one (the edge c -> c + 1)
+    vsel(verts, c, cx, cy);
+    vsel(verts, cn, nx, ny);
     // laser_models.py:283-315
     const double ex = cos(pyaw), ey = sin(pyaw);
     const double ego_ang = atan2(ey, ex);
-    int lo = 0, hi = 0;
+    const double vx = cx - px, vy = cy - py;
+    const double norm = sqrt(vx * vx + vy * vy);
+    const double ux = vx / norm, uy = vy / norm;
+    double angle = ego_ang - atan2(uy, ux);
+    if (angle > F110_PI) angle = angle - 2 * F110_PI;
+    else if (angle < -F110_PI) angle = angle + 2 * F110_PI;
+    const double bang = -angle; // the corner's direction in the scan's frame, [-pi, pi]
+    const int ind = argmin_abs_diff_sorted(a.scan_angles, a.nb, bang);
+    int lo = ind, hi = ind;
+    double bmin = bang, bmax = bang;
+    double neg_max = bang < 0.0 ? bang : -__builtin_inf(), pos_min = bang >= 0.0 ? bang : __builtin_inf();
+    bool nan_any = !(bang == bang);
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const double vx = verts[i][0] - px, vy = verts[i][1] - py;
-        const double norm = sqrt(vx * vx + vy * vy);
-        const double ux = vx / norm, uy = vy / norm;
-        double angle = ego_ang - atan2(uy, ux);
-        if (angle > F110_PI) angle = angle - 2 * F110_PI;
-        else if (angle < -F110_PI) angle = angle + 2 * F110_PI;
-        const int ind = argmin_abs_diff_sorted(a.scan_angles, a.nb, -angle);
-        if (i == 0) { lo = hi = ind; }
-        else { lo = ind < lo ? ind : lo; hi = ind > hi ? ind : hi; }
+    for (int off = 1; off <= 2; off <<= 1) {
+        const int o_lo = __shfl_xor(lo, off), o_hi = __shfl_xor(hi, off);
+        lo = o_lo < lo ? o_lo : lo;
+        hi = o_hi > hi ? o_hi : hi;
+        const double t0 = __shfl_xor(bmin, off), t1 = __shfl_xor(bmax, off), t2 = __shfl_xor(neg_max, off), t3 = __shfl_xor(pos_min, off);
+        bmin = t0 < bmin ? t0 : bmin; bmax = t1 > bmax ? t1 : bmax;
+        neg_max = t2 > neg_max ? t2 : neg_max; pos_min = t3 < pos_min ? t3 : pos_min;
+        nan_any = nan_any || (__shfl_xor((int)nan_any, off) != 0);
     }
-    if (lo > a.nb - 1 || hi > a.nb - 1) { lo = 1; hi = 0; } // only reachable with NaN inputs
-    const double A = pyaw + F110_PI / 2.;
-    o.px = px; o.py = py; o.cA = cos(A); o.sA = sin(A);
-#pragma unroll
-    for (int k = 0; k < 4; k++) { o.v[2 * k] = verts[k][0]; o.v[2 * k + 1] = verts[k][1]; }
+    const bool valid = !(lo > a.nb - 1 || hi > a.nb - 1 || nan_any); // (invalid only with NaN inputs; quad-uniform)
+    // this lane's edge: what get_range computes from the pose and the two corners alone; front-facing edges first
+    int n_front;
     {
-        const double cx = 0.5 * (verts[0][0] + verts[2][0]), cy = 0.5 * (verts[0][1] + verts[2][1]);
-        const double dx = verts[0][0] - verts[2][0], dy = verts[0][1] - verts[2][1];
-        o.qx = cx - px; o.qy = cy - py;
-        o.reach = 0.5 * sqrt(dx * dx + dy * dy) * 1.000001 + 1e-9;
-        if (!(o.reach == o.reach)) o.reach = __builtin_inf(); // NaN poses: no pre-test
+        const double v1x = px - cx, v1y = py - cy;     // laser_models.py:258
+        const double v2x = nx - cx, v2y = ny - cy;     // :259
+        const double cr = v2x * v1y - v2y * v1x;       // cross(v2, v1) :267, :220-230
+        // The car is on the outer side of edge c iff cross(v2, v1) has the sign opposite to the quad's orientation (twice
+        // its signed area, from the diagonals).  cross == 0 (the car on the edge's line) and NaNs count as front-facing.
+        const double orient = (verts[2][0] - verts[0][0]) * (verts[3][1] - verts[1][1]) - (verts[2][1] - verts[0][1]) * (verts[3][0] - verts[1][0]);
+        const bool back = (orient > 0.0 && cr > 0.0) || (orient < 0.0 && cr < 0.0);
+        const int q0 = (threadIdx.x & 63) & ~3;
+        int before_f = 0, before_b = 0, nf = 0;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int be = __shfl((int)back, q0 + e);
+            nf += be ? 0 : 1;
+            if (e < c) { before_f += be ? 0 : 1; before_b += be ? 1 : 0; }
+        }
+        n_front = nf == 0 ? 4 : nf; // (no edge faces a car inside the quad: all take the full test, in their own order)
+        const int pos = nf == 0 ? c : (back ? nf + before_b : before_f);
+        out.r.v1x[pos] = v1x; out.r.v1y[pos] = v1y; out.r.v2x[pos] = v2x; out.r.v2y[pos] = v2y;
+        out.r.cr[pos] = cr;
+        out.r.ax[pos] = cx; out.r.ay[pos] = cy; out.r.bx[pos] = nx; out.r.by[pos] = ny;
     }
-    o.lo = lo; o.hi = hi;
-    // Which chunks can matter.  A beam can only be cut short if its line passes within `reach` of the opponent's
-    // centre (opp_apply's pre-test), i.e. if its direction, modulo pi, is within asin(reach / |q|) of the direction to
-    // the centre.  With the opponent straight behind the car the reference's span is the whole scan (the corner
-    // angles straddle +-pi, laser_models.py:293-315) although only a few dozen beams point at it or away from it:
-    // opp_apply then walks 2..4 chunks instead of 17.  Conservative (margins of a beam increment and 1e-6 rad), so the
-    // beams tested inside the visited chunks -- and the results -- are those of the per-beam pre-test alone.
-    unsigned long long mask = 0ull;
-    if (lo <= hi) {
-        const double qn = sqrt(o.qx * o.qx + o.qy * o.qy);
+    if (c != 0) return;
+    out.r.n_front = n_front; out.r.pad = 0;
+    // cos / sin(yaw + pi/2) = (-sin, cos)(yaw): within an ulp of the reference's cos(fl(fl(yaw + angle) + pi/2)) route, like
+    // the angle-addition form it feeds (f110_device.h, ray_cast_wave)
+    out.r.px = px; out.r.py = py; out.r.cA = -ey; out.r.sA = ex;
+    const double mx = 0.5 * (verts[0][0] + verts[2][0]), my = 0.5 * (verts[0][1] + verts[2][1]);
+    const double ddx = verts[0][0] - verts[2][0], ddy = verts[0][1] - verts[2][1];
+    const double qx = mx - px, qy = my - py;
+    double reach = 0.5 * sqrt(ddx * ddx + ddy * ddy) * 1.000001 + 1e-9;
+    if (!(reach == reach)) reach = __builtin_inf(); // NaN poses: no pre-test
+    out.r.qx = qx; out.r.qy = qy; out.r.reach = reach;
+    int n_iv = 0, iv[2 * OPP_MAX_IV] = {0, -1, 0, -1, 0, -1};
+    if (valid) {
+        const double qn = sqrt(qx * qx + qy * qy);
         const double sa0 = a.scan_angles[0];
         const double incr = (a.scan_angles[a.nb - 1] - sa0) / (double)(a.nb - 1);
-        const bool all = !(qn > o.reach * 1.000001) || !(o.reach < __builtin_inf()) || !(incr > 0.0);
-        if (all) {
-            for (int c = lo >> 6; c <= (hi >> 6); c++) mask |= 1ull << c;
+        // the car inside the opponent's bounding circle (the hull may be anything), NaNs, a degenerate beam table: every beam
+        const bool all = !(qn > reach * 1.000001) || !(reach < __builtin_inf()) || !(incr > 0.0);
+        if (all || !(bmax - bmin > F110_PI)) {
+            // the hull is the arc from the lowest to the highest corner angle: [lo, hi] itself (hull + pi lies outside it)
+            iv[0] = lo; iv[1] = hi; n_iv = 1;
         } else {
-            const double span = asin(o.reach / qn) + 2.0 * incr + 1e-6;
-            const double phi = remainder(atan2(o.qy, o.qx) - pyaw, 2.0 * F110_PI); // direction to the centre in the scan's frame
+            // the corners straddle +-pi: the hull is [-pi, neg_max] + [pos_min, pi], hull + pi the arc around 0 between them
             const double inv = 1.0 / incr;
-            // the direction, its opposite (lines, not rays) and their images one turn away: beam-index intervals
-            for (int k = -2; k <= 2; k++) {
-                const double centre = phi + (double)k * F110_PI;
-                const double a0 = (centre - span - sa0) * inv, a1 = (centre + span - sa0) * inv;
-                if (!(a1 >= (double)lo) || !(a0 <= (double)hi)) continue;
-                const int i0 = a0 > (double)lo ? (int)floor(a0) : lo, i1 = a1 < (double)hi ? (int)ceil(a1) : hi;
+            const double cand[3][2] = {{(double)lo, (neg_max - sa0) * inv + 2.0},
+                                       {(pos_min - F110_PI - sa0) * inv - 2.0, (neg_max + F110_PI - sa0) * inv + 2.0},
+                                       {(pos_min - sa0) * inv - 2.0, (double)hi}};
+            int end = lo - 1;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                double b0 = cand[k][0], b1 = cand[k][1];
+                if (!(b0 == b0) || !(b1 == b1)) { b0 = (double)lo; b1 = (double)hi; }
+                int i0 = b0 > (double)(end + 1) ? (int)floor(b0) : end + 1;
+                const int i1 = b1 < (double)hi ? (int)ceil(b1) : hi;
+                if (i0 < lo) i0 = lo;
                 if (i0 > i1) continue;
-                const int c0 = i0 >> 6, c1 = i1 >> 6;
-                mask |= (~0ull >> (63 - c1)) & ~((1ull << c0) - 1ull);
+                iv[2 * n_iv] = i0; iv[2 * n_iv + 1] = i1; n_iv++;
+                end = i1;
             }
         }
     }
-    o.chunks = mask;
+    int total = 0;
+#pragma unroll
+    for (int k = 0; k < OPP_MAX_IV; k++) {
+        out.iv[2 * k] = iv[2 * k]; out.iv[2 * k + 1] = iv[2 * k + 1];
+        if (k < n_iv) total += iv[2 * k + 1] - iv[2 * k] + 1;
+    }
+    out.n_iv = n_iv; out.total = total;
 }
 
-// One wave per car, walking the 64-beam chunks that some opponent's span touches (most cars see their
-// opponent in a few dozen beams; a wave per (car, chunk) spent its time being launched: 17 waves per car,
-// 16 of them leaving at once).
-__global__ __launch_bounds__(256) void opp_apply_kernel(OppArgs a)
+#ifndef F110_OPP_GROUP
+#define F110_OPP_GROUP 64
+#endif
+constexpr int OPP_GROUP = F110_OPP_GROUP; // lanes per car in opp_apply_kernel (measured at 32 768 cars: 8 lanes 52 us, 16: 33, 32: 27, 64: 23)
+constexpr int OPP_GROUP_MAX = 256; // a pair with more beams than this is walked by the whole wave, not by its group
+
+__global__ __launch_bounds__(256, 8) void opp_apply_kernel(OppArgs a)
 {
-    const int car = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
-    if (car >= a.n_cars) return;
-    const int lane = threadIdx.x & 63, per = a.agents - 1;
-    const OppPair *pairs = a.pairs + (size_t)car * per; // wave-uniform: scalar loads
-    unsigned long long todo = 0ull; // chunks some opponent's span touches AND whose beams can reach it (opp_setup)
-    for (int jj = 0; jj < per; jj++)
-        if (pairs[jj].lo <= pairs[jj].hi) todo |= pairs[jj].chunks;
-    while (todo) {
-        const int chunk = (int)__builtin_ctzll(todo);
-        todo &= todo - 1;
-        const int base = chunk << 6;
-        const int i = base + lane;
-        double best = __builtin_inf();
-        for (int jj = 0; jj < per; jj++) {
-            const OppPair &o = pairs[jj];
-            if (!((o.chunks >> chunk) & 1ull)) continue; // uniform: nothing of this opponent in this chunk
-            if (i < o.lo || i > o.hi || i >= a.nb) continue;
-            const double2 cs = a.beam_cs[i];
-            const double v3x = o.cA * cs.x - o.sA * cs.y, v3y = o.sA * cs.x + o.cA * cs.y;
-            // v3 is the ray's unit normal (laser_models.py:262): |q . v3| is the distance of the opponent's centre
-            // from the ray's line.  Beyond the padded half diagonal no edge can be crossed (every get_range would
-            // return inf), which is the case for ~95 % of the beams when the span is the whole scan.
-            if (!(fabs(o.qx * v3x + o.qy * v3y) <= o.reach)) continue;
-            // The ray's direction is (v3y, -v3x).  If the whole bounding circle lies BEHIND the car along it, every edge
-            // point has a negative ray parameter: get_range rejects it (d1 >= 0, :271) -- unless an edge is exactly
-            // parallel to the ray (denom == 0: the collinear branch answers whatever the direction, :275-280).
-            if (o.qx * v3y - o.qy * v3x < -o.reach) {
-                bool parallel = false;
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const int en = (e + 1) & 3;
-                    const double denom = (o.v[2 * en] - o.v[2 * e]) * v3x + (o.v[2 * en + 1] - o.v[2 * e + 1]) * v3y;
-                    parallel = parallel || !(fabs(denom) > 0.0);
-                }
-                if (!parallel) continue;
-            }
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const int en = (e + 1) & 3;
-                const double r = get_range(o.px, o.py, v3x, v3y, o.v[2 * e], o.v[2 * e + 1], o.v[2 * en], o.v[2 * en + 1]);
-                if (r < best) best = r;
+    __shared__ OppPair s_pair[256 / OPP_GROUP]; // one per group
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int sub = t & (OPP_GROUP - 1), lane = threadIdx.x & 63, wave = threadIdx.x >> 6, grp = threadIdx.x / OPP_GROUP;
+    // (no lane leaves early: long lists are served by all 64 lanes of the wave)
+    const bool in_range = (t / OPP_GROUP) < a.n_cars;
+    const int car = in_range ? t / OPP_GROUP : a.n_cars - 1;
+    const int per = a.agents - 1;
+    float *s32 = a.scans32 ? a.scans32 + (size_t)car * a.nb : nullptr;
+    double *s64 = a.scans64 ? a.scans64 + (size_t)car * a.nb : nullptr;
+    constexpr int WORDS = (int)(sizeof(OppPair) / 4);
+    for (int jj = 0; jj < per; jj++) { // the opponents of a car one after the other: each is an in-place minimum on the same scan
+        // the group's pair into LDS (its lanes read consecutive words: one or two lines per group)
+        {
+            const unsigned *src = reinterpret_cast<const unsigned *>(a.pairs + (size_t)car * per + jj);
+            unsigned *dst = reinterpret_cast<unsigned *>(&s_pair[grp]);
+            for (int w = sub; w < WORDS; w += OPP_GROUP) dst[w] = src[w];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const OppPair *pr = &s_pair[grp];
+        const int total = in_range ? pr->total : 0;
+        const bool longlist = total > OPP_GROUP_MAX; // (group-uniform)
+        if (total > 0 && !longlist) {
+            const int n_iv = pr->n_iv;
+            for (int tt = sub; tt < total; tt += OPP_GROUP) {
+                const int i = opp_iv_beam(pr->iv, n_iv, tt);
+                if (i >= 0 && i < a.nb) opp_test_beam(&pr->r, a.beam_cs, i, s32, s64);
             }
         }
-        if (best < __builtin_inf()) {
-            if (a.scans64) { double *s = a.scans64 + (size_t)car * a.nb + i; if (best < *s) *s = best; }
-            if (a.scans32) { float *s = a.scans32 + (size_t)car * a.nb + i; const float b32 = (float)best; if (b32 < *s) *s = b32; }
+        unsigned long long todo = __builtin_amdgcn_ballot_w64(longlist && sub == 0);
+        while (todo) {
+            const int src_lane = (int)__builtin_ctzll(todo);
+            todo &= todo - 1;
+            const int wcar = __shfl(car, src_lane);
+            const OppPair *wp = &s_pair[(wave * WAVE + src_lane) / OPP_GROUP]; // that group's copy, in this wave's part of the array
+            const int wn = wp->n_iv, wtotal = wp->total;
+            float *w32 = a.scans32 ? a.scans32 + (size_t)wcar * a.nb : nullptr;
+            double *w64 = a.scans64 ? a.scans64 + (size_t)wcar * a.nb : nullptr;
+            for (int tt = lane; tt < wtotal; tt += WAVE) {
+                const int i = opp_iv_beam(wp->iv, wn, tt);
+                if (i >= 0 && i < a.nb) opp_test_beam(&wp->r, a.beam_cs, i, w32, w64);
+            }
         }
+        __builtin_amdgcn_wave_barrier(); // the LDS copies are overwritten by the next opponent's
     }
 }
 
