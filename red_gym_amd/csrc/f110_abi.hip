@@ -76,6 +76,7 @@ struct f110_handle {
     int32_t *d_env_params = nullptr;  // dev [B] params slot of every env; passed to the kernels only when `multi_params`
     bool multi_params = false;
     OppPair *d_opp_pairs = nullptr;   // [N, A-1] opponent ray-cast scratch (never allocated in f110_step)
+    uint8_t *d_was_pending = nullptr; // [B] pending_reset as the step's first kernel found it
     bool has_map = false, bound = false;
     // Bumped whenever a later f110_step would enqueue different kernels or by-value arguments than an earlier one
     // (a table re-allocated, another scan instantiation selected, buffers re-bound): f110_launch_epoch.
@@ -307,6 +308,8 @@ static int alloc_opp_pairs(f110_handle *h)
     const size_t n = (size_t)h->cfg.num_envs * h->cfg.num_agents * (h->cfg.num_agents - 1);
     HIP_TRY(hipMalloc((void **)&h->d_opp_pairs, n * sizeof(OppPair)));
     HIP_TRY(hipMemset(h->d_opp_pairs, 0, n * sizeof(OppPair)));
+    HIP_TRY(hipMalloc((void **)&h->d_was_pending, (size_t)h->cfg.num_envs));
+    HIP_TRY(hipMemset(h->d_was_pending, 0, (size_t)h->cfg.num_envs));
     return F110_OK;
 }
 
@@ -380,7 +383,7 @@ extern "C" void f110_destroy(f110_handle *h)
     DeviceScope on_dev(h->cfg.device);
     (void)hipDeviceSynchronize();
     void *ptrs[] = {h->d_cs, h->d_beam_cs, h->d_noise, h->d_noise_desc, h->d_noise_gen, h->d_env_noise, h->d_scan_angles, h->d_beam_cosines,
-                    h->d_side, h->d_chunk0, h->d_params, h->d_env_params, h->d_opp_pairs, h->d_maps, h->d_env_map, h->d_err};
+                    h->d_side, h->d_chunk0, h->d_params, h->d_env_params, h->d_opp_pairs, h->d_was_pending, h->d_maps, h->d_env_map, h->d_err};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &r : h->retired) { (void)hipFree(r.ptr); (void)hipEventDestroy(r.ev); }
@@ -1462,7 +1465,8 @@ static void sample_lookups(const f110_handle *h, bool sampled_step, ScanArgs &s)
     if (h->prof_on && !sampled_step) s.lookups = nullptr;
 }
 
-// The step of every env: dynamics_kernel -> scan_kernel -> [opp_setup_kernel, opp_apply_kernel] -> env_kernel.  (Two other
+// The step of every env: dynamics_kernel -> scan_kernel -> env_kernel, or for A > 1 -> post_scan_kernel (env bookkeeping and
+// the opponents' set-up side by side) -> opp_apply_kernel.  (Two other
 // forms -- a scan that also closes the step of a one-agent env, and a workgroup per car with a shared beam queue -- were
 // built, held to ==, measured slower at every size and removed: tools/variants/car_group_and_closing_scan.patch,
 // profiles/r03_step_forms.txt.)
@@ -1479,7 +1483,7 @@ static int run_step(f110_handle *h, const double *actions, int reset_only, const
         DynArgs d;
         d.n_cars = N; d.agents = c.num_agents; d.state = b.state; d.steer_buf = b.steer_buf; d.steer_cnt = b.steer_cnt;
         d.noise_step = b.noise_step; d.actions = actions; d.spawn = b.spawn; d.pending_reset = b.pending_reset;
-        d.reset_only = reset_only; d.pose_snap = b.pose_snap; d.in_collision = b.in_collision; d.params = h->d_params; d.env_params = h->multi_params ? h->d_env_params : nullptr;
+        d.was_pending = h->d_was_pending; d.reset_only = reset_only; d.pose_snap = b.pose_snap; d.in_collision = b.in_collision; d.params = h->d_params; d.env_params = h->multi_params ? h->d_env_params : nullptr;
         d.time_step = c.timestep; d.integrator = c.integrator;
         if ((rc = emit(st, (const void *)&dynamics_kernel, dim3((N + 255) / 256), dim3(256), 0, d))) return rc;
     }
@@ -1511,18 +1515,6 @@ static int run_step(f110_handle *h, const double *actions, int reset_only, const
     if (rc) return rc;
     if (prof) h->prof_n++;
 
-    if (c.num_agents > 1) {
-        OppArgs o;
-        memset(&o, 0, sizeof(o));
-        o.n_cars = N; o.agents = c.num_agents; o.nb = c.num_beams; o.state = b.state; o.pose_snap = b.pose_snap;
-        o.in_collision = b.in_collision; o.scan_angles = h->d_scan_angles; o.beam_cs = h->d_beam_cs; o.params = h->d_params; o.env_params = h->multi_params ? h->d_env_params : nullptr;
-        o.pending_reset = b.pending_reset; o.reset_only = reset_only; o.scans32 = b.scans; o.scans64 = b.scans_f64;
-        o.pairs = h->d_opp_pairs;
-        const int npairs = N * (c.num_agents - 1);
-        if ((rc = emit(st, (const void *)&opp_setup_kernel, dim3((4 * npairs + 127) / 128), dim3(128), 0, o))) return rc; // four lanes per pair
-        if ((rc = emit(st, (const void *)&opp_apply_kernel, dim3((int)(((long long)OPP_GROUP * N + 255) / 256)), dim3(256), 0, o))) return rc; // OPP_GROUP lanes per car
-    }
-
     EnvArgs e;
     e.n_envs = c.num_envs; e.agents = c.num_agents; e.ego_idx = c.ego_idx; e.autoreset = c.autoreset;
     e.reset_only = reset_only; e.state = b.state; e.noise_step = b.noise_step; e.pose_snap = b.pose_snap; e.spawn = b.spawn;
@@ -1530,7 +1522,21 @@ static int run_step(f110_handle *h, const double *actions, int reset_only, const
     e.start_rot = b.start_rot; e.near_start = b.near_start; e.toggles = b.toggles; e.lap_counts = b.lap_counts;
     e.lap_times = b.lap_times; e.current_time = b.current_time; e.pending_reset = b.pending_reset; e.done = b.done; e.checkpoint_done = b.checkpoint_done;
     e.time_step = c.timestep; e.params = h->d_params; e.env_params = h->multi_params ? h->d_env_params : nullptr;
-    return emit(st, (const void *)&env_kernel, dim3((c.num_envs + 127) / 128), dim3(128), 0, e);
+    const int env_blocks = (c.num_envs + 127) / 128;
+    if (c.num_agents == 1) return emit(st, (const void *)&env_kernel, dim3(env_blocks), dim3(128), 0, e);
+
+    // A > 1: env bookkeeping and the opponents' set-up side by side in one launch, then the ray cast
+    PostScanArgs ps;
+    memset(&ps, 0, sizeof(ps));
+    ps.e = e; ps.env_blocks = env_blocks;
+    OppArgs &o = ps.o;
+    o.n_cars = N; o.agents = c.num_agents; o.nb = c.num_beams; o.state = b.state; o.pose_snap = b.pose_snap;
+    o.in_collision = b.in_collision; o.scan_angles = h->d_scan_angles; o.beam_cs = h->d_beam_cs; o.params = h->d_params; o.env_params = h->multi_params ? h->d_env_params : nullptr;
+    o.pending_reset = h->d_was_pending; o.reset_only = reset_only; o.scans32 = b.scans; o.scans64 = b.scans_f64;
+    o.pairs = h->d_opp_pairs;
+    const int npairs = N * (c.num_agents - 1);
+    if ((rc = emit(st, (const void *)&post_scan_kernel, dim3(env_blocks + (4 * npairs + 127) / 128), dim3(128), 0, ps))) return rc; // four lanes per pair
+    return emit(st, (const void *)&opp_apply_kernel, dim3((int)(((long long)OPP_GROUP * N + 255) / 256)), dim3(256), 0, ps.o); // OPP_GROUP lanes per car
 }
 
 static Sink make_sink(f110_handle *h, hipStream_t st, std::vector<KernelLaunch> *record)

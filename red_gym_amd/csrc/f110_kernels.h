@@ -508,7 +508,7 @@ struct OppArgs {
     const double2 *beam_cs;   // [nb] {cos, sin}(scan_angles)
     const Params *params;     // [slots, 1 + agents] (see DynArgs): a car sizes its opponents with its OWN params (base_classes.py:221)
     const int32_t *env_params;// [B] or NULL
-    const uint8_t *pending_reset;
+    const uint8_t *pending_reset; // [B] as the step found it (dynamics_kernel's snapshot)
     int reset_only;
     struct OppPair *pairs;    // [N, agents-1] scratch owned by the handle
     float *scans32;           // [N,nb] or NULL
@@ -625,10 +625,9 @@ __device__ inline int opp_iv_beam(const int *iv, int n_iv, int tt)
     return i;
 }
 
-// Four lanes per (car, opponent) pair.
-__global__ __launch_bounds__(128) void opp_setup_kernel(OppArgs a)
+// Four lanes per (car, opponent) pair; t = index of the lane among all pairs' lanes.
+__device__ inline void opp_setup_body(const OppArgs &a, int t)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int p = t >> 2, c = t & 3;
     const int per = a.agents - 1;
     if (p >= a.n_cars * per) return; // (whole quads leave together)
@@ -748,6 +747,8 @@ __global__ __launch_bounds__(128) void opp_setup_kernel(OppArgs a)
     out.n_iv = n_iv; out.total = total;
 }
 
+__global__ __launch_bounds__(128) void opp_setup_kernel(OppArgs a) { opp_setup_body(a, blockIdx.x * blockDim.x + threadIdx.x); }
+
 #ifndef F110_OPP_GROUP
 #define F110_OPP_GROUP 64
 #endif
@@ -814,6 +815,7 @@ struct DynArgs {
     const double *actions;// [N,2] (steer, speed)
     const double *spawn;  // [N,3] or NULL
     const uint8_t *pending_reset; // [B] or NULL
+    uint8_t *was_pending; // [B] or NULL: pending_reset as this step found it (env_kernel clears / re-arms the flag itself)
     int reset_only;
     double *pose_snap;    // [N,3] or NULL
     uint8_t *in_collision;// [N] or NULL: cleared here, set by scan_kernel
@@ -866,6 +868,7 @@ __global__ __launch_bounds__(256) void dynamics_kernel(DynArgs a)
     if (car < 0) return;
     const int env = car / a.agents;
     const bool pend = a.pending_reset && a.pending_reset[env];
+    if (a.was_pending) a.was_pending[env] = pend ? 1 : 0; // (every car of the env stores the same byte)
     double st[7], sb[2];
     int sc;
     double steer, speed;
@@ -1012,9 +1015,8 @@ __global__ __launch_bounds__(128) void check_done_kernel(CheckDoneArgs a)
     a.done[env] = ((a.collisions[c0 + a.ego_idx] != 0) || all_done) ? 1 : 0; // :242
 }
 
-__global__ __launch_bounds__(128) void env_kernel(EnvArgs a)
+__device__ inline void env_body(const EnvArgs &a, int env)
 {
-    const int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= a.n_envs) return;
     const bool pend = a.pending_reset[env] != 0;
     if (a.reset_only && !pend) return;
@@ -1054,6 +1056,24 @@ __global__ __launch_bounds__(128) void env_kernel(EnvArgs a)
     const bool dn = (a.collisions[c0 + a.ego_idx] != 0) || all_done;
     a.done[env] = dn ? 1 : 0;
     if (a.autoreset && dn) a.pending_reset[env] = 1;
+}
+
+__global__ __launch_bounds__(128) void env_kernel(EnvArgs a) { env_body(a, blockIdx.x * blockDim.x + threadIdx.x); }
+
+// A > 1: the env bookkeeping and the opponents' set-up in ONE launch.  Both are small kernels whose time is latency (256 and
+// 2 048 waves), and neither reads what the other writes -- except that env_body zeroes the yaw of a car whose iTTC fired, for
+// which the set-up uses 0 anyway, and clears pending_reset, of which the set-up reads dynamics_kernel's snapshot
+// (OppArgs::pending_reset = was_pending) -- so the first env_blocks workgroups do one and the rest the other, side by side.
+struct PostScanArgs {
+    EnvArgs e;
+    OppArgs o;
+    int env_blocks;
+};
+
+__global__ __launch_bounds__(128) void post_scan_kernel(PostScanArgs a)
+{
+    if ((int)blockIdx.x < a.env_blocks) env_body(a.e, blockIdx.x * blockDim.x + threadIdx.x);
+    else opp_setup_body(a.o, (blockIdx.x - a.env_blocks) * blockDim.x + threadIdx.x);
 }
 
 // ------------------------------------------------------------------ function-level kernels
