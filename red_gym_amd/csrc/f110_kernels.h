@@ -102,8 +102,10 @@ struct ScanDev {
 // resolution is a power of two, so q = x_rot * (1/res) IS the reference's quotient and
 // "x_rot < 0 or x_rot >= width*res" (:79) is exactly "floor(q) outside [0, W)", which the
 // clamp to [-1, W] maps onto the table's border.
+// laser_models.py:71-84 (xy_2_rc): the cell (column ci, row ri) of a point, un-clamped (a saturating conversion: any value
+// outside [0, W) x [0, H) means "out of bounds", which the callers map onto the reference's dt[-1, -1] read).
 template <bool IDENT, bool POW2>
-__device__ inline double dist_lookup(const MapView &m, const double *lds_lut, double x, double y, bool live)
+__device__ inline void cell_index(const MapView &m, double x, double y, int &ci, int &ri)
 {
     double xr = 0, yr = 0, qx, qy;
     if (IDENT && POW2) {
@@ -120,7 +122,7 @@ __device__ inline double dist_lookup(const MapView &m, const double *lds_lut, do
         qy = yr * m.rinv;
     }
     const double fx = floor(qx), fy = floor(qy);
-    int ci = (int)fx, ri = (int)fy; // saturating conversion; the clamp below finishes the job
+    ci = (int)fx; ri = (int)fy; // saturating conversion; the callers' clamp / bounds test finishes the job
     if (!POW2) {
         // int(x_rot/resolution) and the bounds test need the IEEE quotient: x_rot*(1/res) is
         // within ~2e-12 of it, so only quotients within 1e-9 of an integer (where truncation
@@ -135,6 +137,13 @@ __device__ inline double dist_lookup(const MapView &m, const double *lds_lut, do
             }
         }
     }
+}
+
+template <bool IDENT, bool POW2>
+__device__ inline double dist_lookup(const MapView &m, const double *lds_lut, double x, double y, bool live)
+{
+    int ci, ri;
+    cell_index<IDENT, POW2>(m, x, y, ci, ri);
     const int cc = med3_i32(ci, -1, m.W);      // column -1..W (both ends are border cells)
     const int rr = med3_i32(ri, -1, m.H);      // row -1..H
     // Byte offset of cell (rr, cc): strip (cc >> 3) + 1 (arithmetic shift: column -1 is the last column of
@@ -382,6 +391,9 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
 #if defined(F110_TIMELINE)
     { unsigned long long t = wall_clock64(); asm volatile("" : "+v"(t)); if (lane == 0) s_tl[wave][1] = t; }
 #endif
+#if defined(F110_TIMELINE)
+    unsigned tl_wit = 0, tl_wit_dry = 0; // march iterations of the wave so far / when its queue ran dry
+#endif
     unsigned nlook = (unsigned)nbl; // the reference reads the table once per beam before marching
     if (!(d0 > eps && d0 <= max_range)) {
         for (int k = lane; k < nbl; k += WAVE) {
@@ -397,6 +409,9 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
         // 24.40 fixed point of t0w in [0, theta_dis); a NaN / out-of-range yaw falls to the slow path
         const unsigned long long T0 = (t0w >= 0 && t0w < td) ? (unsigned long long)(t0w * 1099511627776.0) : ~0ull;
 
+#if defined(F110_TIMELINE)
+        bool tl_dry = false;
+#endif
         int next = 0;           // wave-uniform: next unassigned slot of the beam order
         bool active = false;
         int beam = -1;          // beam whose result `total` holds (-1: none)
@@ -445,7 +460,13 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
 #if defined(F110_DRAIN_PRIO)
             if (go == 0) __builtin_amdgcn_s_setprio(F110_DRAIN_PRIO); // experiment: a draining wave ends on its longest ray's dependent chain
 #endif
+#if defined(F110_TIMELINE)
+            if (go == 0 && !tl_dry) { unsigned long long t = wall_clock64(); asm volatile("" : "+v"(t)); if (lane == 0) s_tl[wave][1] = t; tl_dry = true; tl_wit_dry = tl_wit; }
+#endif
             do {
+#if defined(F110_TIMELINE)
+                tl_wit++;
+#endif
                 nlook += (unsigned)nact;
                 const double d = dist_lookup<IDENT, POW2>(mv, s_lut, x, y, active);
                 total += d;
@@ -465,7 +486,9 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
     asm volatile("" : "+v"(tl_end));
     if (ra->timeline && lane == 0) {
         unsigned long long *tl = ra->timeline + (size_t)wid * 4;
-        tl[0] = s_tl[wave][0]; tl[1] = s_tl[wave][1]; tl[2] = tl_end; tl[3] = ((unsigned long long)car << 8) | (unsigned)part | ((unsigned long long)wpc << 40);
+        // {start, queue ran dry (or first rays), end}; car << 8 | part | wpc << 40 | iterations after the queue ran dry << 44
+        tl[0] = s_tl[wave][0]; tl[1] = s_tl[wave][1]; tl[2] = tl_end;
+        tl[3] = ((unsigned long long)car << 8) | (unsigned)part | ((unsigned long long)wpc << 40) | ((unsigned long long)min(tl_wit - tl_wit_dry, 0xfffffu) << 44);
     }
 #endif
 

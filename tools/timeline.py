@@ -1,4 +1,4 @@
-"""Per-wave timeline of ONE step's scan / car-group launch (diagnostics build of the library):
+"""Per-wave timeline of ONE step's scan launch (diagnostics build of the library):
     hipcc ... -DF110_TIMELINE -o build_variants/timeline.so ; F110_LIB=build_variants/timeline.so python tools/timeline.py
     [--envs B] [--stages SPEC]
 Prints, in microseconds from the first wave's start: when waves start (percentiles), wave lifetimes by kind (whole
@@ -48,19 +48,14 @@ t0 = buf[:, 0].min()
 start = (buf[:, 0] - t0).astype(np.float64) / 100.0   # 100 MHz ticks -> us
 ready = (buf[:, 1] - t0).astype(np.float64) / 100.0
 end = (buf[:, 2] - t0).astype(np.float64) / 100.0
-group = name == 'group'
-if group:  # car | wave << 20 | nwaves << 24 | iterations when the queue ran dry << 28 | iterations at the end << 46
-    car = (buf[:, 3] & np.uint64(0xfffff)).astype(np.int64)
-    wpc = ((buf[:, 3] >> np.uint64(24)) & np.uint64(0xf)).astype(np.int64)
-    it_dry = ((buf[:, 3] >> np.uint64(28)) & np.uint64(0x3ffff)).astype(np.int64)
-    it_end = ((buf[:, 3] >> np.uint64(46)) & np.uint64(0x3ffff)).astype(np.int64)
-else:
-    wpc = (buf[:, 3] >> np.uint64(40)).astype(np.int64)
-    car = ((buf[:, 3] >> np.uint64(8)) & np.uint64(0xffffffff)).astype(np.int64)
-print('%s %s stages=%r: %d waves, launch ends at %.1f us after the first wave starts' % (B, a.path, a.stages, len(buf), end.max()))
+# car << 8 | part | wpc << 40 | march iterations after the wave's queue ran dry << 44
+wpc = ((buf[:, 3] >> np.uint64(40)) & np.uint64(0xf)).astype(np.int64)
+car = ((buf[:, 3] >> np.uint64(8)) & np.uint64(0xffffffff)).astype(np.int64)
+drain_it = (buf[:, 3] >> np.uint64(44)).astype(np.int64)
+print('%s envs, lib %s, stages=%r: %d waves, launch ends at %.1f us after the first wave starts' % (B, os.path.basename(os.environ.get('F110_LIB', 'default')), a.stages, len(buf), end.max()))
 pc = lambda x: ' '.join('%.1f' % v for v in np.percentile(x, [0, 10, 50, 90, 99, 100]))  # noqa: E731
 print('  wave start      p0/10/50/90/99/100: ' + pc(start))
-print('  prologue (start -> first rays)     : ' + pc(ready - start))
+print('  start -> queue dry (whole life of a wave whose car has no ray to march): ' + pc(ready - start))
 for k in sorted(set(wpc.tolist())):
     m = wpc == k
     print('  %d wave(s)/car: %6d waves, lifetime %s   end %s' % (k, m.sum(), pc((end - start)[m]), pc(end[m])))
@@ -70,15 +65,15 @@ for c, e in zip(car.tolist(), end.tolist()):
     last[c] = max(last.get(c, 0.0), e)
 ce = np.array(list(last.values()))
 print('  car completion  p0/10/50/90/99/100: ' + pc(ce))
-if group:
-    # the drain phase of a wave (queue dry -> last ray done): microseconds per wave iteration, for the waves that end last
-    # (nearly alone on the chip) and for all
-    drain_us, drain_it = end - ready, it_end - it_dry
-    ok = drain_it > 20
-    last = np.argsort(end)[-12:]
-    print('  wave iterations per wave: ' + pc(it_end) + '   of them after the queue ran dry: ' + pc(drain_it))
-    print('  us per iteration in the drain phase, all waves: ' + ' '.join('%.3f' % v for v in np.percentile((drain_us / np.maximum(drain_it, 1))[ok], [10, 50, 90])))
-    print('  the 12 waves that end last: ' + '  '.join('end %.0f us: %d it, drain %d it @ %.3f us' % (end[i], it_end[i], drain_it[i], drain_us[i] / max(drain_it[i], 1)) for i in last))
+# the drain phase of a wave (queue dry -> last ray done): microseconds per march iteration = the dependent chain of ONE
+# table lookup, for all waves and for the waves that end last (nearly alone on the chip)
+drain_us = end - ready
+ok = drain_it > 20
+if ok.sum():
+    print('  march iterations after the queue ran dry: ' + pc(drain_it[ok]))
+    print('  us per iteration in the drain phase, p10/50/90 over waves: ' + ' '.join('%.3f' % v for v in np.percentile((drain_us / np.maximum(drain_it, 1))[ok], [10, 50, 90])))
+    lastw = np.argsort(end)[-12:]
+    print('  the 12 waves that end last: ' + '  '.join('end %.0f us: drain %d it @ %.3f us' % (end[i], drain_it[i], drain_us[i] / max(drain_it[i], 1)) for i in lastw))
 # the longest-living waves: does the car's lookup count (this step / the step before) predict them?
 life = end - start
 top = np.argsort(life)[-12:][::-1]
