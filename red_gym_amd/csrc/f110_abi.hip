@@ -514,7 +514,7 @@ extern "C" int f110_set_tables(f110_handle *h, const double *sines, const double
 
 // Publishes the device tables of a freshly built map in slot `slot` (both pipelines end here).
 static int finish_map(f110_handle *h, int slot, int H, int W, int Hp, size_t n_tiled, double res, double ox, double oy, double oc,
-                      double os, double oob)
+                      double os, double oob, unsigned lut_len)
 {
     f110_handle::MapSlot &sl = h->slots[slot];
     MapDev &m = sl.dev;
@@ -524,6 +524,7 @@ static int finish_map(f110_handle *h, int slot, int H, int W, int Hp, size_t n_t
     m.wres = W * res; // width * resolution (laser_models.py:79)
     m.hres = H * res;
     m.oob = oob;      // dt[-1, -1]
+    m.lut_len = lut_len;
     int e = 0;
     sl.pow2 = std::frexp(res, &e) == 0.5;
     sl.ident = (oc == 1.0 && os == 0.0);
@@ -606,7 +607,7 @@ static int install_map(f110_handle *h, int slot, const double *dt, const uint32_
     lut_lds[SLOT_FAR] = 0.0;          // never used as a distance (OFF_FAR cells take the second table)
     lut_lds[SLOT_BORDER] = dt[n - 1]; // dt[-1, -1]
     if ((rc = upload(&sl.d_lut_lds, lut_lds.data(), lut_lds.size()))) return rc;
-    return finish_map(h, slot, H, W, Hp, n_tiled, res, ox, oy, oc, os, dt[n - 1]);
+    return finish_map(h, slot, H, W, Hp, n_tiled, res, ox, oy, oc, os, dt[n - 1], (unsigned)lut.size());
 }
 
 // ---------------------------------------------------------------- map pipeline on the device
@@ -717,7 +718,7 @@ static int install_map_occupancy_dev(f110_handle *h, int slot, const uint8_t *ma
     lut_lds[SLOT_FAR] = 0.0;
     lut_lds[SLOT_BORDER] = oob;
     if ((rc = upload(&sl.d_lut_lds, lut_lds.data(), lut_lds.size()))) return rc;
-    return finish_map(h, slot, H, W, Hp, n_tiled, res, ox, oy, oc, os, oob);
+    return finish_map(h, slot, H, W, Hp, n_tiled, res, ox, oy, oc, os, oob, n_lut);
 }
 
 
@@ -883,6 +884,7 @@ static int noise_publish(f110_handle *h, hipStream_t st)
     NoiseDesc d;
     d.base = h->d_noise; d.cap = h->noise_cap; d.mask = h->noise_cap - 1;
     d.lo = h->noise_on ? h->noise_lo : 0;
+    d.slots = h->noise_slots;
     d.hi = h->noise_on ? h->noise_hi : 0x7fffffffffffffffll; // noise off: every row is the row of zeros
     hipLaunchKernelGGL(noise_publish_kernel, dim3(1), dim3(1), 0, st, h->d_noise_desc, d);
     HIP_TRY(hipGetLastError());
@@ -1206,6 +1208,19 @@ extern "C" int f110_assign_noise(f110_handle *h, const int32_t *slot_of_env)
     return F110_OK;
 }
 
+#if defined(F110_BOUNDS)
+// bounds-checked build only: one checked access that is out of range on purpose, so that a test can see the report arrive
+__global__ void bounds_selftest_kernel(uint32_t *err, int idx, int len) { F110_BCHK(idx < len, BT_SELFTEST, err); }
+extern "C" int f110_bounds_selftest(f110_handle *h)
+{
+    if (!h) return fail(F110_E_INVALID, "f110_bounds_selftest: null handle");
+    ON_DEVICE(h->cfg.device);
+    hipLaunchKernelGGL(bounds_selftest_kernel, dim3(1), dim3(1), 0, nullptr, h->d_err, 7, 7);
+    HIP_TRY(hipGetLastError());
+    return F110_OK;
+}
+#endif
+
 extern "C" int f110_device_errors(f110_handle *h, uint32_t *flags)
 {
     if (!h || !flags) return fail(F110_E_INVALID, "f110_device_errors: null argument");
@@ -1483,7 +1498,7 @@ static int run_step(f110_handle *h, const double *actions, int reset_only, const
         DynArgs d;
         d.n_cars = N; d.agents = c.num_agents; d.state = b.state; d.steer_buf = b.steer_buf; d.steer_cnt = b.steer_cnt;
         d.noise_step = b.noise_step; d.actions = actions; d.spawn = b.spawn; d.pending_reset = b.pending_reset;
-        d.was_pending = h->d_was_pending; d.reset_only = reset_only; d.pose_snap = b.pose_snap; d.in_collision = b.in_collision; d.params = h->d_params; d.env_params = h->multi_params ? h->d_env_params : nullptr;
+        d.was_pending = h->d_was_pending; d.reset_only = reset_only; d.pose_snap = b.pose_snap; d.in_collision = b.in_collision; d.params = h->d_params; d.env_params = h->multi_params ? h->d_env_params : nullptr; d.param_slots = h->param_slots; d.dev_err = h->d_err;
         d.time_step = c.timestep; d.integrator = c.integrator;
         if ((rc = emit(st, (const void *)&dynamics_kernel, dim3((N + 255) / 256), dim3(256), 0, d))) return rc;
     }
@@ -1521,7 +1536,7 @@ static int run_step(f110_handle *h, const double *actions, int reset_only, const
     e.in_collision = b.in_collision; e.collisions = b.collisions; e.collision_idx = b.collision_idx;
     e.start_rot = b.start_rot; e.near_start = b.near_start; e.toggles = b.toggles; e.lap_counts = b.lap_counts;
     e.lap_times = b.lap_times; e.current_time = b.current_time; e.pending_reset = b.pending_reset; e.done = b.done; e.checkpoint_done = b.checkpoint_done;
-    e.time_step = c.timestep; e.params = h->d_params; e.env_params = h->multi_params ? h->d_env_params : nullptr;
+    e.time_step = c.timestep; e.params = h->d_params; e.env_params = h->multi_params ? h->d_env_params : nullptr; e.param_slots = h->param_slots; e.dev_err = h->d_err;
     const int env_blocks = (c.num_envs + 127) / 128;
     if (c.num_agents == 1) return emit(st, (const void *)&env_kernel, dim3(env_blocks), dim3(128), 0, e);
 
@@ -1533,7 +1548,7 @@ static int run_step(f110_handle *h, const double *actions, int reset_only, const
     o.n_cars = N; o.agents = c.num_agents; o.nb = c.num_beams; o.state = b.state; o.pose_snap = b.pose_snap;
     o.in_collision = b.in_collision; o.scan_angles = h->d_scan_angles; o.beam_cs = h->d_beam_cs; o.params = h->d_params; o.env_params = h->multi_params ? h->d_env_params : nullptr;
     o.pending_reset = h->d_was_pending; o.reset_only = reset_only; o.scans32 = b.scans; o.scans64 = b.scans_f64;
-    o.pairs = h->d_opp_pairs;
+    o.pairs = h->d_opp_pairs; o.param_slots = h->param_slots; o.dev_err = h->d_err;
     const int npairs = N * (c.num_agents - 1);
     if ((rc = emit(st, (const void *)&post_scan_kernel, dim3(env_blocks + (4 * npairs + 127) / 128), dim3(128), 0, ps))) return rc; // four lanes per pair
     return emit(st, (const void *)&opp_apply_kernel, dim3((int)(((long long)OPP_GROUP * N + 255) / 256)), dim3(256), 0, ps.o); // OPP_GROUP lanes per car
@@ -1894,7 +1909,7 @@ extern "C" int f110_update_pose(f110_handle *h, double *state, double *steer_buf
     DynArgs d;
     memset(&d, 0, sizeof(d));
     d.n_cars = n; d.agents = 1; d.state = state; d.steer_buf = steer_buf; d.steer_cnt = steer_cnt; d.actions = actions;
-    d.params = h->d_params; d.time_step = h->cfg.timestep; d.integrator = h->cfg.integrator;
+    d.params = h->d_params; d.param_slots = h->param_slots; d.dev_err = h->d_err; d.time_step = h->cfg.timestep; d.integrator = h->cfg.integrator;
     hipLaunchKernelGGL(dynamics_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, d);
     HIP_TRY(hipGetLastError());
     return F110_OK;

@@ -28,6 +28,23 @@ __device__ inline unsigned long long vote(bool p) { return __builtin_amdgcn_ball
 constexpr int WAVE = 64;
 // bits of the device error word (f110_device_errors; include/f110_hip.h F110_DEVERR_*)
 constexpr uint32_t DEVERR_NOISE_WINDOW = 1u, DEVERR_BOUNDS = 2u;
+
+// Bounds-checked debug build (-DF110_BOUNDS; `tools/build_variant.sh bounds -DF110_BOUNDS`, selected with F110_LIB; SURVEY 5
+// "race detection / sanitizers": GPU AddressSanitizer is not available on this pool, the CPU oracle runs under ASan / UBSan).
+// Every index a kernel of the step path forms from DATA -- a cell code, a rank, a slot number, a beam number, a noise row --
+// is checked against its table before use; a violation ORs DEVERR_BOUNDS and the table's bit (8 + BT_*) into the handle's
+// device error word (f110_device_errors) and the access is redirected to a valid element, so the run goes on and the
+// report names the table.  The whole -m gpu suite is run against this build once per round (profiles/r04_bounds_build.txt).
+enum { BT_LUT_CODE, BT_CELLS_FAR, BT_LUT_RANK, BT_DT, BT_NOISE_BEAM, BT_CS_TABLE, BT_CHUNK_ORDER, BT_MAP_SLOT, BT_NOISE_SLOT,
+       BT_PARAMS_SLOT, BT_SCAN_STORE, BT_OPP_BEAM, BT_STAGE_LIST, BT_SELFTEST };
+#if defined(F110_BOUNDS)
+#define F110_BCHK(ok, table, errp) \
+    do { if (!(ok)) { uint32_t *e_ = (errp); if (e_) atomicOr(e_, DEVERR_BOUNDS | (1u << (8 + (table)))); } } while (0)
+#define F110_BOUNDS_ONLY(...) __VA_ARGS__
+#else
+#define F110_BCHK(ok, table, errp) do { } while (0)
+#define F110_BOUNDS_ONLY(...)
+#endif
 constexpr int TL_MAX_WAVES = 8; // (diagnostics builds: per-wave stamps of a workgroup)
 #ifndef F110_SCAN_WAVES
 #define F110_SCAN_WAVES 2
@@ -65,11 +82,12 @@ struct MapDev {
     const uint16_t *cells_far; // same layout: rank (<= 65534) of the cells marked OFF_FAR, 65535 = fp64 table
     unsigned cells_bytes;
     unsigned strip_bytes;   // Hp * 16, Hp = H + 2 rounded up to a multiple of 8
-    const double *lut;      // [<=65534] resolution*sqrt(d2_k), indexed by rank k
+    const double *lut;      // [lut_len <= 65535] resolution*sqrt(d2_k), indexed by rank k
     const double *lut_lds;  // [LUT_LDS] image staged in LDS: lut[0..SLOT_FAR-1], unused, dt[-1,-1]
     const double *dt;       // [H*W] exact fp64 distance table (escape path, rarely touched)
     int H, W;
     double res, rinv, ox, oy, oc, os, wres, hres, oob; // oob = dt[H-1][W-1]
+    unsigned lut_len;       // entries of lut
 };
 
 // device-side view of MapDev with the cell table behind a buffer resource descriptor
@@ -81,8 +99,10 @@ struct MapView {
     int H, W;
     double res, rinv, ox, oy, oc, os, wres, hres;
     double nox, noy; // -ox * rinv, -oy * rinv (exact when rinv is a power of two)
+    F110_BOUNDS_ONLY(uint32_t *err = nullptr; unsigned cells_bytes = 0;)
     __device__ void init(const MapDev &m)
     {
+        F110_BOUNDS_ONLY(cells_bytes = m.cells_bytes;)
         strip_bytes = m.strip_bytes; row_bias = m.strip_bytes + 16u; strip_m16 = m.strip_bytes - 16u; desc = &m; H = m.H; W = m.W; res = m.res; rinv = m.rinv;
         ox = m.ox; oy = m.oy; oc = m.oc; os = m.os; wres = m.wres; hres = m.hres;
         nox = -m.ox * m.rinv; noy = -m.oy * m.rinv;
@@ -161,7 +181,12 @@ __device__ inline double dist_lookup(const MapView &m, const double *lds_lut, do
     // occupying the L1 tag pipeline
     off = live ? off : 0xffffffffu;
     // buffer load: 32-bit per-lane offset against a scalar descriptor
-    const unsigned code = (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(m.cells_rsrc, (int)off, 0, 0);
+    unsigned code = (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(m.cells_rsrc, (int)off, 0, 0);
+#if defined(F110_BOUNDS)
+    F110_BCHK(!live || off + 2u <= m.cells_bytes, BT_LUT_CODE, m.err);
+    F110_BCHK(code <= OFF_BORDER && (code & 7u) == 0u, BT_LUT_CODE, m.err);
+    code = code <= OFF_BORDER ? (code & ~7u) : 0u;
+#endif
     // common case: the loaded value IS the LDS byte offset of the distance: one ds_read_b64
     double d = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(lds_lut) + code);
     // pin the LDS read: otherwise the compiler folds it and the rare global reads below
@@ -172,7 +197,17 @@ __device__ inline double dist_lookup(const MapView &m, const double *lds_lut, do
         if (far) {
             const MapDev *dp = m.desc;
             asm volatile("" : "+s"(dp)); // opaque: the loads below stay here instead of being hoisted to the kernel entry
-            const unsigned rank = *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(dp->cells_far) + (size_t)off);
+#if defined(F110_BOUNDS)
+            F110_BCHK(off + 2u <= dp->cells_bytes, BT_CELLS_FAR, m.err);
+            if (off + 2u > dp->cells_bytes) off = 0u;
+#endif
+            unsigned rank = *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(dp->cells_far) + (size_t)off);
+#if defined(F110_BOUNDS)
+            F110_BCHK(rank == CODE_ESC || rank < dp->lut_len, BT_LUT_RANK, m.err);
+            if (rank != CODE_ESC && rank >= dp->lut_len) rank = 0u;
+            F110_BCHK(rank != CODE_ESC || ((unsigned)rr < (unsigned)m.H && (unsigned)cc < (unsigned)m.W), BT_DT, m.err); // (a border cell never carries the far marker)
+            if (rank == CODE_ESC && !((unsigned)rr < (unsigned)m.H && (unsigned)cc < (unsigned)m.W)) rank = 0u;
+#endif
             d = (rank != CODE_ESC) ? dp->lut[rank] : dp->dt[(size_t)(unsigned)rr * (unsigned)m.W + (unsigned)cc];
         }
     }
@@ -314,7 +349,13 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
     }
     // the car's map (wave-uniform: scalar loads); waves past the last car still help to stage the LUT
     const int car_c = rare->car_base + min(car, a.n_cars - 1);
-    const MapDev &md = a.maps[a.env_map ? a.env_map[car_c / a.agents] : 0];
+    F110_BCHK(rare->n_stages >= 1 && rare->n_stages <= SCAN_MAX_STAGES, BT_STAGE_LIST, rare->dev_err);
+    int map_slot = a.env_map ? a.env_map[car_c / a.agents] : 0;
+#if defined(F110_BOUNDS)
+    F110_BCHK((unsigned)map_slot < 64u /* F110_MAX_MAPS */, BT_MAP_SLOT, rare->dev_err);
+    if ((unsigned)map_slot >= 64u) map_slot = 0;
+#endif
+    const MapDev &md = a.maps[map_slot];
     {   // LDS image of the LUT prepared by the host (slot SLOT_BORDER = dt[-1,-1]): 16-B copies
         const double2 *src = reinterpret_cast<const double2 *>(md.lut_lds);
         double2 *dst = reinterpret_cast<double2 *>(s_lut);
@@ -328,6 +369,7 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
     MapView mv;
     mv.cells_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(md.cells), 0, (int)md.cells_bytes, 0x00020000);
     mv.init(md);
+    F110_BOUNDS_ONLY(mv.err = rare->dev_err;)
     if (car >= a.n_cars) return;
     car += rare->car_base; // (from here on the car's index in the shard)
     // this wave's slice of the car's beam queue: chunk positions part, part+wpc, ...
@@ -354,7 +396,11 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
         const NoiseDesc nd = *rare->noise;
         const long long row = (long long)a.noise_step[car];
         const int32_t *en = rare->env_noise;
-        const long long slot = en ? (long long)en[car / a.agents] : 0ll;
+        long long slot = en ? (long long)en[car / a.agents] : 0ll;
+#if defined(F110_BOUNDS)
+        F110_BCHK(slot >= 0 && slot < nd.slots, BT_NOISE_SLOT, rare->dev_err);
+        if (!(slot >= 0 && slot < nd.slots)) slot = 0;
+#endif
         if (__builtin_expect(row < nd.lo || row >= nd.hi, 0)) {
             // the host keeps the table ahead of every car (Engine._ensure_noise); a row outside it is reported, never silent
             if (lane == 0 && rare->dev_err) atomicOr(rare->dev_err, DEVERR_NOISE_WINDOW);
@@ -369,6 +415,10 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
     // stores, iTTC (:189-217).  nzv / sdv: noise and side distance of the beam, loaded by
     // the caller ahead of time.
     auto emit = [&](int i, double tot, double nzv, double sdv) {
+#if defined(F110_BOUNDS)
+        F110_BCHK((unsigned)i < (unsigned)nb, BT_SCAN_STORE, rare->dev_err);
+        if ((unsigned)i >= (unsigned)nb) return;
+#endif
         double v = __builtin_fmin(tot, max_range); // :143-144 (a NaN total, i.e. a NaN pose, also clamps)
         if (STEP) v += nzv;
         if (o32) *reinterpret_cast<float *>(reinterpret_cast<char *>(o32) + (size_t)((unsigned)i * 4u)) = (float)v;
@@ -397,7 +447,12 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
     unsigned nlook = (unsigned)nbl; // the reference reads the table once per beam before marching
     if (!(d0 > eps && d0 <= max_range)) {
         for (int k = lane; k < nbl; k += WAVE) {
-            const int i = s_chunk0[(k >> 6) * wpc + part] + (k & 63);
+            F110_BCHK((k >> 6) * wpc + part < MAX_CHUNKS, BT_CHUNK_ORDER, rare->dev_err);
+            int i = s_chunk0[((k >> 6) * wpc + part) & (MAX_CHUNKS - 1)] + (k & 63);
+#if defined(F110_BOUNDS)
+            F110_BCHK((unsigned)i < (unsigned)nb, BT_NOISE_BEAM, rare->dev_err);
+            if ((unsigned)i >= (unsigned)nb) i = 0;
+#endif
             const double2 v = STEP ? ns[i] : make_double2(0.0, 0.0);
             emit(i, d0, v.x, v.y);
         }
@@ -431,11 +486,20 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
                 const int k = next + rank;
                 const bool take = k < nbl;
                 const int kk = take ? k : 0;
-                const int b = s_chunk0[(kk >> 6) * wpc + part] + (kk & 63);
+                F110_BCHK((kk >> 6) * wpc + part < MAX_CHUNKS, BT_CHUNK_ORDER, rare->dev_err);
+                int b = s_chunk0[((kk >> 6) * wpc + part) & (MAX_CHUNKS - 1)] + (kk & 63);
+#if defined(F110_BOUNDS)
+                F110_BCHK((unsigned)b < (unsigned)nb, BT_NOISE_BEAM, rare->dev_err);
+                if ((unsigned)b >= (unsigned)nb) b = 0;
+#endif
                 const double2 nsv = STEP ? *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(ns) + (size_t)((unsigned)b * 16u))
                                          : make_double2(0.0, 0.0);
                 const double nzv = nz, sdv = sd;
-                const int ti = beam_theta_index(T0, t0w, b, a.scan);
+                int ti = beam_theta_index(T0, t0w, b, a.scan);
+#if defined(F110_BOUNDS)
+                F110_BCHK((unsigned)ti < (unsigned)a.scan.cs_len, BT_CS_TABLE, rare->dev_err);
+                if ((unsigned)ti >= (unsigned)a.scan.cs_len) ti = 0;
+#endif
                 const double2 cs = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(a.scan.cs) + (size_t)((unsigned)ti * 16u)); // second round trip, overlapped with emit()
                 if (beam >= 0) emit(beam, total, nzv, sdv);
                 beam = -1;
@@ -536,7 +600,21 @@ struct OppArgs {
     struct OppPair *pairs;    // [N, agents-1] scratch owned by the handle
     float *scans32;           // [N,nb] or NULL
     double *scans64;          // [N,nb] or NULL
+    int param_slots;          // (bounds-checked build only)
+    uint32_t *dev_err;
 };
+
+// the params slot of an env (DynArgs::params): checked in the bounds build
+__device__ inline int params_slot_of(const int32_t *env_params, int env, int param_slots, uint32_t *dev_err)
+{
+    int sl = env_params ? env_params[env] : 0;
+#if defined(F110_BOUNDS)
+    F110_BCHK((unsigned)sl < (unsigned)param_slots, BT_PARAMS_SLOT, dev_err);
+    if ((unsigned)sl >= (unsigned)param_slots) sl = 0;
+#endif
+    (void)param_slots; (void)dev_err;
+    return sl;
+}
 
 // exact "n1 / d1 < n2 / d2" for non-negative numerators and positive denominators: the rounded products decide unless
 // they are equal, then the exact residuals of the two products do (fma).  No overflow / underflow for physical ranges.
@@ -579,6 +657,7 @@ struct OppPair {
 
 __device__ inline void opp_test_beam(const OppPairRegs *o, const double2 *__restrict__ beam_cs, int i, float *s32, double *s64)
 {
+    // (callers pass 0 <= i < num_beams: checked there, and reported by the bounds-checked build)
     // (*o lives in LDS: its fields are read where they are used, edge by edge, so that few of them are live at a time and
     // the kernel keeps 8 waves per SIMD -- its time is memory latency, which only more waves hide)
     const double2 cs = beam_cs[i];
@@ -663,7 +742,7 @@ __device__ inline void opp_setup_body(const OppArgs &a, int t)
     // an iTTC hit zeroes the yaw before the ray cast (base_classes.py:245); env_kernel writes the zero into the state later
     const double px = st[0], py = st[1], pyaw = a.in_collision[car] ? 0.0 : st[4];
     const double *op = a.pose_snap + (size_t)(a0 + j) * 3;
-    const Params &P = a.params[(size_t)(a.env_params ? a.env_params[env] : 0) * (a.agents + 1) + 1 + self];
+    const Params &P = a.params[(size_t)params_slot_of(a.env_params, env, a.param_slots, a.dev_err) * (a.agents + 1) + 1 + self];
     double verts[4][2];
     get_vertices(op[0], op[1], op[2], P.v[P_LENGTH], P.v[P_WIDTH], verts);
     const int cn = (c + 1) & 3;
@@ -807,6 +886,7 @@ __global__ __launch_bounds__(256, 8) void opp_apply_kernel(OppArgs a)
             const int n_iv = pr->n_iv;
             for (int tt = sub; tt < total; tt += OPP_GROUP) {
                 const int i = opp_iv_beam(pr->iv, n_iv, tt);
+                F110_BCHK(i >= 0 && i < a.nb, BT_OPP_BEAM, a.dev_err);
                 if (i >= 0 && i < a.nb) opp_test_beam(&pr->r, a.beam_cs, i, s32, s64);
             }
         }
@@ -849,6 +929,8 @@ struct DynArgs {
     const int32_t *env_params;  // [B] params slot of every env, or NULL (all envs on slot 0)
     double time_step;
     int integrator;
+    int param_slots;            // slots `params` holds   \ read by the bounds-checked build only
+    uint32_t *dev_err;          // device error word      /
 };
 
 // The single-track model switches to its kinematic form below 0.5 m/s (dynamic_models.py:152): a wavefront that holds
@@ -917,7 +999,7 @@ __global__ __launch_bounds__(256) void dynamics_kernel(DynArgs a)
         steer = a.actions[(size_t)car * 2];
         speed = a.actions[(size_t)car * 2 + 1];
     }
-    const Params P = a.params[(size_t)(a.env_params ? a.env_params[env] : 0) * (a.agents + 1) + 1 + car % a.agents];
+    const Params P = a.params[(size_t)params_slot_of(a.env_params, env, a.param_slots, a.dev_err) * (a.agents + 1) + 1 + car % a.agents];
     update_pose(st, sb, sc, steer, speed, P, a.time_step, a.integrator);
 #pragma unroll
     for (int i = 0; i < 7; i++) a.state[(size_t)car * 7 + i] = st[i];
@@ -954,6 +1036,8 @@ struct EnvArgs {
     const Params *params;     // [slots, 1 + agents] (see DynArgs): entry 0 of the env's slot sizes the GJK quads
     const int32_t *env_params;// [B] or NULL
     double time_step;
+    int param_slots;          // (bounds-checked build only)
+    uint32_t *dev_err;
 };
 
 // collision_models.py:185-212 on A <= 8 quads held in registers/scratch
@@ -1045,7 +1129,7 @@ __device__ inline void env_body(const EnvArgs &a, int env)
     if (a.reset_only && !pend) return;
     const int A = a.agents, c0 = env * A;
     // Simulator.check_collision (base_classes.py:529-543) on the post-integration poses
-    const Params &SP = a.params[(size_t)(a.env_params ? a.env_params[env] : 0) * (A + 1)]; // Simulator.params (:542)
+    const Params &SP = a.params[(size_t)params_slot_of(a.env_params, env, a.param_slots, a.dev_err) * (A + 1)]; // Simulator.params (:542)
     collision_multiple_dev(a.pose_snap + (size_t)c0 * 3, A, SP.v[P_LENGTH], SP.v[P_WIDTH],
                            a.collisions + c0, a.collision_idx + c0);
     for (int i = 0; i < A; i++) {

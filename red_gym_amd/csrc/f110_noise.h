@@ -33,6 +33,7 @@ typedef unsigned __int128 u128;
 struct NoiseDesc {
     const double2 *base;
     long long mask, cap, lo, hi;
+    long long slots; // slots the table holds (read by the bounds-checked build only)
 };
 
 // generator of one slot: t = the LCG state whose output is the NEXT raw value of the stream

@@ -546,8 +546,14 @@ class Engine(object):
     def close(self):
         if getattr(self, '_h', None) is not None and self._h:
             torch.cuda.synchronize(self.device)
+            flags = self.device_errors() if os.environ.get('F110_CHECK_DEVICE_ERRORS') == '1' else 0
             self.lib.f110_destroy(self._h)
             self._h = None
+            if flags:
+                # (set for the run of the test suite against the bounds-checked build: no handle may end its life with a
+                # device-side complaint nobody read)
+                raise RuntimeError('f110 device error word 0x%x at close (bit 0: noise row outside the table, bit 1: an index '
+                                   'check of the bounds-checked build failed, bits 8..: which table)' % flags)
 
     def __del__(self):
         try:
