@@ -43,6 +43,105 @@ def test_track_mask_matches_numpy(closed):
     assert np.array_equal(got, want)
 
 
+def _track_mask(pts, closed, H, W, x0, y0, pixel, offset, half):
+    from red_gym_amd import _lib
+    d = torch.as_tensor(np.ascontiguousarray(pts, dtype=np.float64), device='cuda')
+    out = torch.empty((H, W), dtype=torch.uint8, device='cuda')
+    _lib.check(_lib.load().f110_track_mask(d.data_ptr(), len(pts), closed, H, W, x0, y0, pixel, offset, half, out.data_ptr(),
+                                           torch.cuda.current_stream().cuda_stream))
+    return out.cpu().numpy()
+
+
+def _pixel_centres(H, W, x0, y0, pixel):
+    ix, iy = np.meshgrid(np.arange(W), np.arange(H))
+    return x0 + (ix + 0.5) * pixel, y0 + (iy + 0.5) * pixel
+
+
+def test_track_walls_of_a_circle_are_two_circles():
+    """Analytic case (not the kernel's own formula): a circular centre line of radius R has walls on the circles R - offset
+    and R + offset, each half a stroke thick.  Every pixel that is clearly inside a wall ring (by more than a pixel diagonal
+    of slack) must be wall, every pixel clearly outside must be free, and both rings must be closed."""
+    H = W = 400
+    pixel, R, offset, half = 0.375, 45.0, 10.0, 0.625          # the generator's units: 600 / 1600 per pixel, WIDTH 10, 3.33 px stroke
+    th = np.linspace(0.0, 2 * np.pi, 720, endpoint=False)
+    pts = np.column_stack([75.0 + R * np.cos(th), 75.0 + R * np.sin(th)])
+    got = _track_mask(pts, 1, H, W, 0.0, 0.0, pixel, offset, half)
+    px, py = _pixel_centres(H, W, 0.0, 0.0, pixel)
+    r = np.hypot(px - 75.0, py - 75.0)
+    ring = np.minimum(np.abs(r - (R - offset)), np.abs(r - (R + offset)))     # distance to the nearer wall circle
+    slack = 0.02                                                # sagitta of the 720-gon (0.0004) + float noise; pixel centres are exact
+    assert (got[ring < half - slack] == 0).all()               # inside a wall ring: wall
+    assert (got[ring > half + slack] == 1).all()               # outside: free
+    # closed rings: walking around each wall circle, every sample point's pixel is wall
+    for rad in (R - offset, R + offset):
+        a = np.linspace(0, 2 * np.pi, 4000)
+        cx = np.floor((75.0 + rad * np.cos(a)) / pixel).astype(int)
+        cy = np.floor((75.0 + rad * np.sin(a)) / pixel).astype(int)
+        assert (got[cy, cx] == 0).all()
+    # and the corridor between them is free along the centre line
+    cx = np.floor(pts[:, 0] / pixel).astype(int); cy = np.floor(pts[:, 1] / pixel).astype(int)
+    assert (got[cy, cx] == 1).all()
+
+
+def test_track_walls_of_a_straight_open_line_are_a_stadium():
+    """Analytic case: an OPEN straight centre line from A to B: the walls are the two parallels at distance `offset` and the
+    two half circles of radius `offset` round the ends (the set at distance `offset` from a segment), half a stroke thick."""
+    H, W = 240, 520
+    pixel, offset, half = 0.375, 10.0, 0.625
+    A, B = np.array([30.0, 45.0]), np.array([160.0, 45.0])
+    pts = np.stack([A + (B - A) * t for t in np.linspace(0, 1, 14)])          # collinear points: the same segment
+    got = _track_mask(pts, 0, H, W, 0.0, 0.0, pixel, offset, half)
+    px, py = _pixel_centres(H, W, 0.0, 0.0, pixel)
+    t = np.clip((px - A[0]) / (B[0] - A[0]), 0.0, 1.0)
+    dist = np.hypot(px - (A[0] + t * (B[0] - A[0])), py - A[1])               # distance to the segment, closed form
+    band = np.abs(dist - offset)
+    assert (got[band < half - 1e-6] == 0).all() and (got[band > half + 1e-6] == 1).all()
+    # the two parallels
+    for yy in (A[1] - offset, A[1] + offset):
+        cx = np.floor(np.linspace(A[0], B[0], 900) / pixel).astype(int)
+        assert (got[int(np.floor(yy / pixel)), cx] == 0).all()
+    # the round caps: points at distance `offset` beyond each end
+    for end, sgn in ((A, -1.0), (B, 1.0)):
+        a = np.linspace(-np.pi / 2, np.pi / 2, 400)
+        cx = np.floor((end[0] + sgn * offset * np.cos(a)) / pixel).astype(int)
+        cy = np.floor((end[1] + offset * np.sin(a)) / pixel).astype(int)
+        assert (got[cy, cx] == 0).all()
+
+
+def test_generated_track_walls_keep_their_distance_from_the_centre_line():
+    """Invariant on a real generated track, checked with an independent tool: scipy's exact EDT of the rasterised centre
+    line.  Every wall pixel lies WIDTH +- (stroke / 2 + 1 px) from the centre line, and every pixel that close to that
+    distance band's middle is a wall (so the walls are complete loops on both sides)."""
+    from scipy.ndimage import distance_transform_edt
+    from red_gym_amd import trackgen
+    t = trackgen.generate(11, device='cuda')
+    wall = t.free.cpu().numpy() == 0
+    cl = t.centerline_units
+    x0, y0 = trackgen.raster_frame(cl)
+    # rasterise the closed centre line densely (10 samples per pixel of length)
+    nxt = np.roll(cl, -1, axis=0)
+    seg = np.hypot(*(nxt - cl).T)
+    line = np.ones((trackgen.MAP_PIXELS, trackgen.MAP_PIXELS), dtype=bool)
+    for a, b, L in zip(cl, nxt, seg):
+        n = max(2, int(L / trackgen.UNITS_PER_PIXEL * 10))
+        p = a + (b - a) * np.linspace(0, 1, n)[:, None]
+        ix = np.floor((p[:, 0] - x0) / trackgen.UNITS_PER_PIXEL).astype(int)
+        iy = np.floor((p[:, 1] - y0) / trackgen.UNITS_PER_PIXEL).astype(int)
+        ok = (ix >= 0) & (ix < trackgen.MAP_PIXELS) & (iy >= 0) & (iy < trackgen.MAP_PIXELS)
+        line[iy[ok], ix[ok]] = False
+    d_px = distance_transform_edt(line)                                    # pixels to the nearest centre-line pixel
+    d_units = d_px * trackgen.UNITS_PER_PIXEL
+    half = 0.5 * trackgen.STROKE_PIXELS * trackgen.UNITS_PER_PIXEL
+    tol = half + 1.5 * trackgen.UNITS_PER_PIXEL                           # raster of the line (<= 1 px) + pixel-centre offset
+    assert wall.sum() > 5000
+    assert (np.abs(d_units[wall] - trackgen.WIDTH) <= tol).all()
+    core = np.abs(d_units - trackgen.WIDTH) <= max(half - 1.5 * trackgen.UNITS_PER_PIXEL, 0.0)
+    # (where the track bends sharply the inner offset curve self-intersects: a pixel can be WIDTH from one stretch of the
+    # centre line and nearer to another -- it is then not at distance WIDTH from the LINE; the EDT is the distance to the line,
+    # so `core` already excludes those)
+    assert core.sum() > 1000 and wall[core].all()
+
+
 def test_generated_track_is_a_drivable_loop():
     from red_gym_amd import F110VecEnv, workload, trackgen
     B = 256
