@@ -244,6 +244,13 @@ int f110_reset(f110_handle *h, const double *poses_dev, const uint8_t *mask_dev,
  * ignore their action and perform reset(spawn) + zero-action step instead. */
 int f110_step(f110_handle *h, const double *actions_dev, void *stream);
 
+/* One env's observation gathered into ONE fp64 row on the device (the single-env Gym facade copies it to the host with
+ * one transfer instead of one per field): out_dev[f110_pack_env_size(h)] =
+ *   [A*7 state | A collisions | A lap_times | A lap_counts | A toggles | current_time | done | A*num_beams scans]
+ * (scans from scans_f64 when bound, else the fp32 scans widened).  Enqueued on `stream`, no synchronisation. */
+int64_t f110_pack_env_size(f110_handle *h);
+int f110_pack_env(f110_handle *h, int32_t env, double *out_dev, void *stream);
+
 /* Tuning / test hook: how a scan launch maps wavefronts to cars, as "cars:lg,cars:lg,..." in launch order with one
  * "*" for the remaining cars: a car of a stage gets 2^lg wavefronts (lg = 0..3; several short-lived waves per car pay
  * for small batches and at the end of a launch).  NULL or "" restores the built-in choice (or the F110_STAGES

@@ -78,6 +78,8 @@ SYMBOLS = {
     'f110_bind': [_VP, C.POINTER(Buffers)],
     'f110_reset': [_VP, _VP, _VP, _VP],
     'f110_step': [_VP, _VP, _VP],
+    'f110_pack_env_size': [_VP],
+    'f110_pack_env': [_VP, _I32, _VP, _VP],
     'f110_set_scan_stages': [_VP, C.c_char_p],
     'f110_launch_epoch': [_VP, C.POINTER(C.c_int64)],
     'f110_graph_create': [_VP, _VP, _I32, C.POINTER(_VP)],
@@ -136,6 +138,7 @@ def load():
         fn.restype = C.c_int
     lib.f110_last_error.restype = C.c_char_p
     lib.f110_pure_pursuit_workspace.restype = C.c_int64
+    lib.f110_pack_env_size.restype = C.c_int64
     lib.f110_destroy.restype = None
     lib.f110_bitmap_destroy.restype = None
     lib.f110_graph_destroy.restype = None

@@ -1604,6 +1604,29 @@ extern "C" int f110_step(f110_handle *h, const double *actions, void *stream)
     return run_step(h, actions, 0, make_sink(h, (hipStream_t)stream));
 }
 
+// ---------------------------------------------------------------- one env's observation in one buffer
+extern "C" int64_t f110_pack_env_size(f110_handle *h)
+{
+    if (!h) return 0;
+    return (int64_t)h->cfg.num_agents * (11 + h->cfg.num_beams) + 2;
+}
+
+extern "C" int f110_pack_env(f110_handle *h, int32_t env, double *out_dev, void *stream)
+{
+    int rc = check_ready(h, "f110_pack_env");
+    if (rc) return rc;
+    if (!out_dev || env < 0 || env >= h->cfg.num_envs) return fail(env < 0 || env >= h->cfg.num_envs ? F110_E_INDEX : F110_E_INVALID, "f110_pack_env: env %d of %d, out %p", env, h->cfg.num_envs, (void *)out_dev);
+    const f110_buffers &b = h->bufs;
+    PackArgs a;
+    a.env = env; a.agents = h->cfg.num_agents; a.nb = h->cfg.num_beams; a.state = b.state; a.collisions = b.collisions; a.lap_times = b.lap_times;
+    a.lap_counts = b.lap_counts; a.toggles = b.toggles; a.current_time = b.current_time; a.done = b.done; a.scans64 = b.scans_f64; a.scans32 = b.scans;
+    a.out = out_dev;
+    const int n = (int)f110_pack_env_size(h);
+    hipLaunchKernelGGL(pack_env_kernel, dim3(std::min((n + 255) / 256, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return F110_OK;
+}
+
 // ---------------------------------------------------------------- the step as a HIP graph built by the library
 struct f110_graph {
     f110_handle *h = nullptr;

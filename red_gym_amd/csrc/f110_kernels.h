@@ -1183,6 +1183,39 @@ __global__ __launch_bounds__(128) void post_scan_kernel(PostScanArgs a)
     else opp_setup_body(a.o, (blockIdx.x - a.env_blocks) * blockDim.x + threadIdx.x);
 }
 
+// ------------------------------------------------------------------ one env's observation in one buffer
+// The single-env facade (red_gym_amd.F110Env = the reference's Gym API on a batch of one) returns NumPy / Python objects
+// every step: instead of a device -> host copy per field, one kernel gathers env `env` into one fp64 row
+//   [A*7 state | A collisions | A lap_times | A lap_counts | A toggles | current_time | done | A*nb scans]
+// (every small field is exactly representable in fp64) and ONE copy takes it to the host.
+struct PackArgs {
+    int env, agents, nb;
+    const double *state; const uint8_t *collisions; const double *lap_times; const int32_t *lap_counts; const int32_t *toggles;
+    const double *current_time; const uint8_t *done; const double *scans64; const float *scans32;
+    double *out;
+};
+
+__global__ __launch_bounds__(256) void pack_env_kernel(PackArgs a)
+{
+    const int A = a.agents, c0 = a.env * A;
+    const int n_small = 11 * A + 2, n = n_small + A * a.nb;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        double v;
+        if (i < 7 * A) v = a.state[(size_t)c0 * 7 + i];
+        else if (i < 8 * A) v = (double)a.collisions[c0 + i - 7 * A];
+        else if (i < 9 * A) v = a.lap_times[c0 + i - 8 * A];
+        else if (i < 10 * A) v = (double)a.lap_counts[c0 + i - 9 * A];
+        else if (i < 11 * A) v = (double)a.toggles[c0 + i - 10 * A];
+        else if (i == 11 * A) v = a.current_time[a.env];
+        else if (i == 11 * A + 1) v = (double)a.done[a.env];
+        else {
+            const size_t k = (size_t)c0 * a.nb + (size_t)(i - n_small);
+            v = a.scans64 ? a.scans64[k] : (double)a.scans32[k];
+        }
+        a.out[i] = v;
+    }
+}
+
 // ------------------------------------------------------------------ function-level kernels
 // dynamic_models.py:91-121 / :124-176 right-hand sides (the reference's KAT surface)
 __global__ void rhs_kernel(const double *x, const double *u, int n, int kinematic, const Params *params, double *f)

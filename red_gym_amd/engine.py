@@ -522,6 +522,20 @@ class Engine(object):
         self._keep_tracks = (tracks, track_of_car)
         return out.view(self.B, self.A, 2) if state is None else out
 
+    @on_own_device
+    def pack_env(self, env=0):
+        """Env `env`'s observation as ONE pinned host fp64 row (f110_pack_env + one device -> host copy + a stream
+        synchronisation): [A*7 state | A collisions | A lap_times | A lap_counts | A toggles | current_time | done | A*nb scans].
+        The returned NumPy array is a view of a buffer that the next call overwrites."""
+        if getattr(self, '_pack_dev', None) is None:
+            n = int(self.lib.f110_pack_env_size(self._h))
+            self._pack_dev = torch.empty((n,), dtype=torch.float64, device=self.device)
+            self._pack_host = torch.empty((n,), dtype=torch.float64).pin_memory()
+        _lib.check(self.lib.f110_pack_env(self._h, int(env), _ptr(self._pack_dev), self._stream()))
+        self._pack_host.copy_(self._pack_dev, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        return self._pack_host.numpy()
+
     def set_scan_stages(self, spec=None):
         """Wave -> car mapping of the scan launches (f110_set_scan_stages): e.g. '*:-2,6144:0,2048:2'."""
         _lib.check(self.lib.f110_set_scan_stages(self._h, None if spec is None else spec.encode()))

@@ -58,15 +58,12 @@ class F110Env(_Base):
         self.render_obs = None
 
     def _collect(self):
-        t = self._vec.eng.t
         A = self.num_agents
-        # two device -> host hops per step: every small field packed into one fp64 row (all of them are exactly
-        # representable: counters, flags, fp64 times), and the scans
-        small = torch.cat([t['state'][0].reshape(-1), t['collisions'][0].to(torch.float64), t['lap_times'][0],
-                           t['lap_counts'][0].to(torch.float64), t['toggles'][0].to(torch.float64),
-                           t['current_time'][0:1], t['done'][0:1].to(torch.float64)]).cpu().numpy()
-        scans = t['scans_f64'][0].cpu().numpy()
-        st = small[:7 * A].reshape(A, 7)
+        # ONE device -> host hop per step: a gather kernel packs every field of the env into one fp64 row (counters, flags
+        # and fp64 times are all exactly representable) in a pinned buffer
+        small = self._vec.eng.pack_env(0)
+        scans = small[11 * A + 2:].reshape(A, -1)
+        st = small[:7 * A].reshape(A, 7).copy()
         o = 7 * A
         self.collisions = small[o:o + A].copy()
         self.lap_times = small[o + A:o + 2 * A].copy()
