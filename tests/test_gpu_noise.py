@@ -220,3 +220,39 @@ def test_a_row_outside_the_table_is_reported(assets):
         assert e.lib.f110_step(e._h, C.c_void_p(a.data_ptr()), None) == 0
     assert e.device_errors() == 1 and e.device_errors() == 0      # reported once, then cleared
     e.close()
+
+
+def test_every_env_its_own_vehicle_at_batch_scale(assets):
+    """4 096 envs, each constructed with its own params dict (4 096 params slots, identity assignment) and one of 64 seeds:
+    a sample of envs spread over the batch `==` their own oracle Envs over 12 steps (what BASELINE's domain-randomised use
+    looks like: SURVEY 8 f3)."""
+    import torch
+    from red_gym_amd import F110VecEnv, workload
+    from red_gym_amd.engine import DEFAULT_PARAMS
+    B, A, T = 4096, 1, 12
+    rng = np.random.default_rng(99)
+    pars = []
+    for e in range(B):
+        p = dict(DEFAULT_PARAMS)
+        p.update(mu=float(rng.uniform(0.6, 1.3)), C_Sf=float(rng.uniform(3.5, 5.5)), C_Sr=float(rng.uniform(4.0, 6.0)),
+                 m=float(rng.uniform(3.0, 4.5)), I=float(rng.uniform(0.035, 0.06)), a_max=float(rng.uniform(6.0, 10.0)))
+        pars.append(p)
+    seeds = [1000 + (e * 7) % 64 for e in range(B)]
+    env = F110VecEnv(B, map=os.path.join(assets, 'example_map'), num_agents=A, seed=seeds, params=pars, autoreset=False, keep_f64_scans=True)
+    poses = workload.spawn_poses(B, A)
+    acts = workload.action_pool(4, B, A)
+    env.reset(poses)
+    sample = [0, 1, 63, 64, 65, 1000, 2047, 2048, 3000, 4095]
+    sc = _scanner(assets)
+    ors = {e: oracle.Env(sc, A, params=pars[e], noise=oracle.noise_table(seeds[e], T + 3)) for e in sample}
+    for e in sample:
+        ors[e].reset(poses[e])
+    for k in range(T):
+        obs = env.step(torch.as_tensor(acts[k % 4], device='cuda'))[0]
+        st, s64 = _np(env.state), _np(obs['scans_f64'])
+        for e in sample:
+            o = ors[e].step(acts[k % 4][e])
+            assert np.allclose(st[e], o['state'], rtol=0, atol=1e-9), (k, e)
+            assert np.allclose(s64[e], o['scans'], rtol=0, atol=1e-9), (k, e)
+    assert env.eng.device_errors() == 0
+    env.close()

@@ -34,6 +34,27 @@ def test_bench_with_a_forced_one_rank_rccl_group():
     assert len(out['median_of_repeats']['ms_per_step']) == 3
 
 
+def test_bench_as_a_torchrun_rank_with_rccl():
+    """The driver's N > 1 form -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...` -- with N = 1 and the forced group: RANK / WORLD_SIZE / MASTER_* come from the
+    launcher, the rendezvous is the launcher's, the collectives are RCCL's."""
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT', 'F110_BENCH_BACKEND')}
+    env.update(F110_BENCH_FORCE_GROUP='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    p = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+                        '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--envs', '2048', '--steps', '5',
+                        '--warmup', '2', '--sustained', '0', '--no-cpu-baseline'],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, text=True)
+    assert p.returncode == 0, p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 1 and out['steps'] == 5 and len(out['per_rank_ms']) == 1 and len(out['devices']) == 1
+
+
 def test_two_handles_interleaved_on_two_streams(assets):
     """Two F110VecEnv handles in one process, stepped alternately on two streams, give what each gives alone: a handle
     restores the caller's current device after every allocating call and launches only on the caller's stream."""
