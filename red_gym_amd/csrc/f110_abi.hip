@@ -882,10 +882,10 @@ static void noise_recompute_hi(f110_handle *h)
 static int noise_publish(f110_handle *h, hipStream_t st)
 {
     NoiseDesc d;
-    d.base = h->d_noise; d.cap = h->noise_cap; d.mask = h->noise_cap - 1;
-    d.lo = h->noise_on ? h->noise_lo : 0;
-    d.slots = h->noise_slots;
-    d.hi = h->noise_on ? h->noise_hi : 0x7fffffffffffffffll; // noise off: every row is the row of zeros
+    d.base = h->d_noise; d.cap = (int)h->noise_cap; d.mask = (int)(h->noise_cap - 1);
+    d.lo = h->noise_on ? (int)std::min(h->noise_lo, (long long)0x7fffffff) : 0;
+    d.slots = h->noise_slots; d.pad = 0;
+    d.hi = h->noise_on ? (int)std::min(h->noise_hi, (long long)0x7fffffff) : 0x7fffffff; // noise off: every row is the row of zeros
     hipLaunchKernelGGL(noise_publish_kernel, dim3(1), dim3(1), 0, st, h->d_noise_desc, d);
     HIP_TRY(hipGetLastError());
     return F110_OK;
@@ -896,6 +896,7 @@ static int noise_publish(f110_handle *h, hipStream_t st)
 static int noise_resize(f110_handle *h, int slots, long long cap)
 {
     const int nb = h->cfg.num_beams;
+    if ((long long)slots * cap >= 0x7fffffffll) return fail(F110_E_INVALID, "noise table: %d slots x %lld rows exceed 2^31 rows", slots, cap);
     HIP_TRY(hipDeviceSynchronize());
     noise_reap(h, true);
     double2 *nt = nullptr;

@@ -333,6 +333,10 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
     const int nb = a.scan.nb;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int wid = blockIdx.x * SCAN_WAVES + wave; // wave-uniform (scalar)
+    // the noise table's descriptor: a pointer chase (kernarg -> descriptor), started here so that it completes behind the
+    // staging of the LUT instead of at the head of the car's first refill
+    NoiseDesc nd;
+    if (STEP) nd = *rare->noise;
     // wave -> (car, part of its beam queue).  Kept to one extra argument and shifts: this kernel sits at
     // the 80-SGPR budget of 8 waves/SIMD, and a scalar spilled inside the refill loop costs ~3 % of the launch.
     int wpc, car, part;
@@ -393,10 +397,9 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
     const double2 *__restrict__ ns = nullptr;
     if (STEP) {
         // the car's noise row: row `scans since its reset` of its env's slot (a ring of nd.cap rows per slot)
-        const NoiseDesc nd = *rare->noise;
-        const long long row = (long long)a.noise_step[car];
+        const int row = a.noise_step[car];
         const int32_t *en = rare->env_noise;
-        long long slot = en ? (long long)en[car / a.agents] : 0ll;
+        int slot = en ? en[car / a.agents] : 0;
 #if defined(F110_BOUNDS)
         F110_BCHK(slot >= 0 && slot < nd.slots, BT_NOISE_SLOT, rare->dev_err);
         if (!(slot >= 0 && slot < nd.slots)) slot = 0;
@@ -405,7 +408,7 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
             // the host keeps the table ahead of every car (Engine._ensure_noise); a row outside it is reported, never silent
             if (lane == 0 && rare->dev_err) atomicOr(rare->dev_err, DEVERR_NOISE_WINDOW);
         }
-        ns = nd.base + (size_t)(slot * nd.cap + (row & nd.mask)) * (size_t)nb;
+        ns = nd.base + (size_t)(unsigned)(slot * nd.cap + (row & nd.mask)) * (size_t)(unsigned)nb; // (slots * cap rows < 2^31: noise_resize)
     }
     float *o32 = a.out_f32 ? a.out_f32 + (size_t)car * nb : nullptr;
     double *o64 = a.out_f64 ? a.out_f64 + (size_t)car * nb : nullptr;

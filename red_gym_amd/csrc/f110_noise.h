@@ -32,8 +32,8 @@ typedef unsigned __int128 u128;
 // are present (a ring once lo > 0); noise off: cap = 1, one row of zeros.
 struct NoiseDesc {
     const double2 *base;
-    long long mask, cap, lo, hi;
-    long long slots; // slots the table holds (read by the bounds-checked build only)
+    int mask, cap, lo, hi; // (a car's row counter is an int32: f110_buffers.noise_step)
+    int slots, pad;        // slots the table holds (read by the bounds-checked build only)
 };
 
 // generator of one slot: t = the LCG state whose output is the NEXT raw value of the stream
