@@ -104,7 +104,26 @@ class Ranks(object):
                     s.bind(('127.0.0.1', 0))
                     os.environ['MASTER_PORT'] = str(s.getsockname()[1])
             if backend == 'nccl':
-                dist.init_process_group('nccl', rank=self.rank, world_size=self.world, device_id=device)
+                try:
+                    dist.init_process_group('nccl', rank=self.rank, world_size=self.world, device_id=device)
+                    import torch
+                    probe = torch.zeros(1, device=device)          # communicators are created lazily: make RCCL prove itself
+                    dist.all_reduce(probe)                          # here, where a failure can still be handled
+                    torch.cuda.synchronize(device)
+                except Exception as e:  # noqa: BLE001 -- whatever RCCL raises on this node
+                    # The ranks only meet for barriers and two tiny gathers around the timed region (no collective on the
+                    # step path), so a node where RCCL cannot start still gives the same measurement over gloo; the JSON
+                    # line says which one synchronised the ranks.
+                    sys.stderr.write('bench.py: rank %d: RCCL failed to start (%s: %s); synchronising the ranks over gloo\n'
+                                     % (self.rank, type(e).__name__, e))
+                    try:
+                        dist.destroy_process_group()
+                    except Exception:  # noqa: BLE001
+                        pass
+                    self.backend = 'gloo'
+                    port = int(os.environ['MASTER_PORT']) + 1      # a fresh store: the failed group may have left keys behind
+                    dist.init_process_group('gloo', init_method='tcp://%s:%d' % (os.environ['MASTER_ADDR'], port),
+                                            rank=self.rank, world_size=self.world)
             else:
                 dist.init_process_group(backend, rank=self.rank, world_size=self.world)
 
@@ -444,6 +463,7 @@ def main(argv=None):
                           'envs_per_gpu': B, 'agents': A, 'num_beams': 1080, 'map': 'example_map',
                           'sharding': 'independent env shards, no collective on the step path'},
                'per_rank_ms': [t / K * 1e3 for t in per_rank], 'devices': names,
+               'rank_sync': ('rccl' if ranks.backend == 'nccl' else ranks.backend) if ranks.grouped else 'none (one rank)',
                'roofline': roof, 'sustained': sustained}
         if repeats:
             out['median_of_repeats'] = repeats

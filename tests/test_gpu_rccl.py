@@ -32,6 +32,7 @@ def test_bench_with_a_forced_one_rank_rccl_group():
     assert len(out['devices']) == 1 and out['devices'][0]           # the device name came back through all_gather
     assert out['value'] > 1e6 and out['roofline']['launches'] >= 2
     assert len(out['median_of_repeats']['ms_per_step']) == 3
+    assert out['rank_sync'] == 'rccl', p.stderr[-2000:]        # RCCL itself ran (bench.py falls back to gloo only if it cannot start)
 
 
 def test_bench_as_a_torchrun_rank_with_rccl():
@@ -53,6 +54,7 @@ def test_bench_as_a_torchrun_rank_with_rccl():
     assert len(lines) == 1, p.stdout
     out = json.loads(lines[0])
     assert out['n_gpus'] == 1 and out['steps'] == 5 and len(out['per_rank_ms']) == 1 and len(out['devices']) == 1
+    assert out['rank_sync'] == 'rccl', p.stderr[-2000:]
 
 
 def test_two_handles_interleaved_on_two_streams(assets):
