@@ -9,11 +9,9 @@
 //   * random_standard_normal (numpy/random/src/distributions/distributions.c): 256-layer ziggurat -- 99.3 % of the draws
 //     are one table compare; the wedge test uses exp(), the tail (|x| > 3.654, 0.026 % of the draws) log1p();
 //   * random_normal: loc + scale * x.
-// The stream is sequential (a draw consumes one raw value, or more after a rejection), so ONE WAVEFRONT per seed walks it:
-// lane j holds the generator state of raw position p + j (LCG jump-ahead), all lanes test their candidate at once, the
-// run of leading fast accepts is written as consecutive beams, the first rejected candidate -- if any -- is resolved by
-// the sequential rule on a broadcast state, and the window is re-based by the number of raw values consumed (lanes that
-// fall off the front jump 64 positions ahead, then the wave rotates).  Exactness: every accepted value outside the tail
+// The stream is sequential (a draw consumes one raw value, or more after a rejection), so ONE WAVEFRONT per seed walks it,
+// 64 raw values at a time (noise_rows_kernel below; lane j holds the generator state of raw position p + j by LCG
+// jump-ahead).  Exactness: every accepted value outside the tail
 // is the product of an integer and a table entry (no library call); the tail's log1p comes from the device math library
 // and may differ from glibc's by an ulp of a 1e-2-scaled term (tests/test_gpu_noise.py counts how often).
 #pragma once
@@ -81,90 +79,123 @@ struct NoiseGenArgs {
 };
 
 // One wavefront per noise slot (grid = slots).
+//
+// The stream is walked in WINDOWS of 64 raw values, one per lane, and a window is always consumed whole: every lane treats
+// its raw value as a candidate (99.3 % are accepted by one table compare); a rejected candidate resolves itself
+// SPECULATIVELY, stepping a private copy of its own generator state through the raw values it would consume if it really
+// were a candidate (wedge: one; tail: two per trial) -- no lane needs another lane's value.  Which lanes ARE candidates is
+// then settled in stream order with a few scalar operations: a candidate's extra raws are not candidates (they are skipped,
+// into the next window if need be: `skip`), everything else is.  The accepted candidates are numbered by a prefix count and
+// stored as consecutive beams.  The window then advances by exactly 64 positions (one 128-bit multiply-add per lane), so
+// there is no re-basing shuffle and the only state carried from window to window is (skip, beams produced).
 __global__ __launch_bounds__(64) void noise_rows_kernel(NoiseGenArgs a)
 {
     __shared__ unsigned long long s_ki[256];
     __shared__ double s_wi[256], s_fi[256];
+    __shared__ double s_side[4096]; // the side distances that ride with the noise (num_beams <= 4096): a lone wave cannot hide a global load per window
     const int lane = threadIdx.x, slot = blockIdx.x;
     const NoiseGen g = a.gen[slot];
     if (!g.on || g.rows >= a.r1) return; // (uniform)
     for (int i = lane; i < 256; i += 64) { s_ki[i] = ZIG_KI[i]; s_wi[i] = ZIG_WI[i]; s_fi[i] = ZIG_FI[i]; }
+    for (int i = lane; i < a.nb; i += 64) s_side[i] = a.side[i];
     __syncthreads();
     const u128 M = pcg_mult(), inc = ((u128)g.inc_hi << 64) | (u128)g.inc_lo;
     // 64 steps at once: s -> A * s + C
     u128 A = 1, C = 0;
     for (int i = 0; i < 64; i++) { A *= M; C = C * M + inc; }
     u128 T = ((u128)g.t_hi << 64) | (u128)g.t_lo;
-    for (int i = 0; i < lane; i++) T = T * M + inc; // lane j: the state of raw position p + j
+    for (int i = 0; i < lane; i++) T = T * M + inc; // lane j: the state whose output is raw value p + j
     const double std = g.std;
     const int nb = a.nb;
-    for (long long row = g.rows; row < a.r1; row++) {
-        const bool keep = row >= a.lo;
-        double2 *dst = a.base + ((size_t)slot * (size_t)a.cap + (size_t)(row & a.mask)) * (size_t)nb;
-        int o = 0; // beams of this row produced so far
-        while (o < nb) {
-            // distributions.c random_standard_normal: r = next_uint64; idx = r & 0xff; r >>= 8; sign = r & 1;
-            // rabs = (r >> 1) & 0x000fffffffffffff; x = rabs * wi[idx]; if (sign) x = -x; if (rabs < ki[idx]) return x;
-            unsigned long long r = pcg_out(T);
-            const int idx = (int)(r & 0xffull);
-            r >>= 8;
-            const bool neg = (r & 1ull) != 0;
-            const unsigned long long rabs = (r >> 1) & 0x000fffffffffffffull;
-            double x = (double)rabs * s_wi[idx];
-            if (neg) x = -x;
-            const bool fast = rabs < s_ki[idx];
-            const unsigned long long bad = __builtin_amdgcn_ballot_w64(!fast);
-            const int nfast = bad ? (int)__builtin_ctzll(bad) : 64; // leading lanes whose candidate is accepted at once
-            const int m = nfast < nb - o ? nfast : nb - o;
-            if (lane < m && keep) dst[o + lane] = make_double2(0.0 + std * x, a.side[o + lane]); // random_normal: loc + scale * x
-            o += m;
-            int consumed = m;
-            if (o < nb && m == nfast && nfast < 64) {
-                // lane nfast's candidate takes the slow path: the sequential rule on a broadcast copy of its state
-                const int f = nfast;
-                u128 Q = shfl128(T, f);
-                const int idx_f = __shfl(idx, f);
-                const unsigned long long rabs_f = shfl64(rabs, f);
-                const double x_f = __longlong_as_double((long long)shfl64((unsigned long long)__double_as_longlong(x), f));
-                int extra = 0;
-                bool emit;
-                double val;
-                if (idx_f == 0) {
+    const unsigned long long below = (1ull << lane) - 1ull;
+    long long row = g.rows;
+    int o = 0;     // beams of `row` produced so far
+    int skip = 0;  // leading raw values of this window that belong to a candidate of an earlier window
+    for (;;) {
+        // distributions.c random_standard_normal: r = next_uint64; idx = r & 0xff; r >>= 8; sign = r & 1;
+        // rabs = (r >> 1) & 0x000fffffffffffff; x = rabs * wi[idx]; if (sign) x = -x; if (rabs < ki[idx]) return x;
+        unsigned long long r = pcg_out(T);
+        const int idx = (int)(r & 0xffull);
+        r >>= 8;
+        const bool neg = (r & 1ull) != 0;
+        const unsigned long long rabs = (r >> 1) & 0x000fffffffffffffull;
+        double val = (double)rabs * s_wi[idx];
+        if (neg) val = -val;
+        const bool fast = rabs < s_ki[idx];
+        int extras = 0;   // raw values this lane consumes beyond its own IF it is a candidate
+        bool emits = true; // ... and whether it then yields a value (a rejected wedge draw does not: the draw starts over)
+        const unsigned long long slow = __builtin_amdgcn_ballot_w64(!fast);
+        if (slow != 0ull) {
+            if (!fast) {
+                u128 Q = T;
+                if (idx == 0) {
                     // tail: xx = -inv_r * log1p(-U), yy = -log1p(-U) until yy + yy > xx * xx
                     for (;;) {
                         Q = Q * M + inc; const double u1 = pcg_double(pcg_out(Q));
                         Q = Q * M + inc; const double u2 = pcg_double(pcg_out(Q));
-                        extra += 2;
+                        extras += 2;
                         const double xx = -ZIG_NOR_INV_R * log1p(-u1);
                         const double yy = -log1p(-u2);
-                        if (yy + yy > xx * xx) { val = ((rabs_f >> 8) & 1ull) ? -(ZIG_NOR_R + xx) : ZIG_NOR_R + xx; break; }
+                        if (yy + yy > xx * xx) { val = ((rabs >> 8) & 1ull) ? -(ZIG_NOR_R + xx) : ZIG_NOR_R + xx; break; }
                     }
-                    emit = true;
                 } else {
                     // wedge: ((fi[idx-1] - fi[idx]) * U + fi[idx]) < exp(-0.5 * x * x) ? return x : draw again
                     Q = Q * M + inc; const double u = pcg_double(pcg_out(Q));
-                    extra = 1;
-                    emit = ((s_fi[idx_f - 1] - s_fi[idx_f]) * u + s_fi[idx_f]) < exp(-0.5 * x_f * x_f);
-                    val = x_f;
+                    extras = 1;
+                    emits = ((s_fi[idx - 1] - s_fi[idx]) * u + s_fi[idx]) < exp(-0.5 * val * val);
                 }
-                if (emit) {
-                    if (lane == 0 && keep) dst[o] = make_double2(0.0 + std * val, a.side[o]);
-                    o += 1;
-                }
-                consumed = f + 1 + extra;
-            }
-            // re-base the window: lane i must hold the state of raw position p + consumed + i
-            while (consumed >= 64) { T = A * T + C; consumed -= 64; }
-            if (consumed > 0) {
-                if (lane < consumed) T = A * T + C;
-                T = shfl128(T, (lane + consumed) & 63);
             }
         }
-    }
-    if (lane == 0) {
-        a.gen[slot].t_lo = (unsigned long long)T;
-        a.gen[slot].t_hi = (unsigned long long)(T >> 64);
-        a.gen[slot].rows = a.r1;
+        // ---- which lanes are candidates: in stream order, a candidate's extras are not
+        unsigned long long skipped = skip >= 64 ? ~0ull : ((1ull << skip) - 1ull);
+        int carry = skip > 64 ? skip - 64 : 0;
+        unsigned long long m = slow & ~skipped;
+        while (m) {
+            const int l = (int)__builtin_ctzll(m);
+            m &= m - 1ull;
+            const int e = __builtin_amdgcn_readlane(extras, l);
+            int end = l + e;
+            if (end > 63) { carry = carry > end - 63 ? carry : end - 63; end = 63; }
+            if (end > l) {
+                const unsigned long long hi = end == 63 ? ~0ull : ((1ull << (end + 1)) - 1ull);
+                const unsigned long long range = hi & ~((2ull << l) - 1ull); // positions l+1 .. end
+                skipped |= range;
+                m &= ~range;
+            }
+        }
+        const unsigned long long emitm = ~skipped & __builtin_amdgcn_ballot_w64(emits);
+        const int n_emit = __popcll(emitm);
+        const bool mine = (emitm >> lane) & 1ull;
+        const int rank = __popcll(emitm & below);
+        const long long left = (a.r1 - row) * (long long)nb - (long long)o; // beams this launch still has to produce
+        const bool last = (long long)n_emit >= left;
+        // ---- store: beam number o + rank of row `row`, running on into the next rows
+        if (mine && (!last || (long long)rank < left)) {
+            int gb = o + rank;
+            long long rw = row;
+            while (gb >= nb) { gb -= nb; rw++; }
+            if (rw >= a.lo)
+                a.base[((size_t)slot * (size_t)a.cap + (size_t)(rw & a.mask)) * (size_t)nb + gb] = make_double2(0.0 + std * val, s_side[gb]); // random_normal: loc + scale * x
+        }
+        if (last) {
+            // the launch ends inside this window: the stream stands behind the candidate that produced the last beam
+            unsigned long long mm = emitm;
+            for (long long i = 1; i < left; i++) mm &= mm - 1ull;
+            const int L = (int)__builtin_ctzll(mm);
+            const int q = L + 1 + __builtin_amdgcn_readlane(extras, L); // (extras is 0 for a fast candidate)
+            u128 Tq = shfl128(T, q < 63 ? q : 63);
+            for (int i = 63; i < q; i++) Tq = Tq * M + inc;
+            if (lane == 0) {
+                a.gen[slot].t_lo = (unsigned long long)Tq;
+                a.gen[slot].t_hi = (unsigned long long)(Tq >> 64);
+                a.gen[slot].rows = a.r1;
+            }
+            return;
+        }
+        o += n_emit;
+        while (o >= nb) { o -= nb; row++; }
+        skip = carry;
+        T = A * T + C;
     }
 }
 

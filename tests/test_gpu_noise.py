@@ -256,3 +256,45 @@ def test_every_env_its_own_vehicle_at_batch_scale(assets):
             assert np.allclose(s64[e], o['scans'], rtol=0, atol=1e-9), (k, e)
     assert env.eng.device_errors() == 0
     env.close()
+
+
+def test_slot_api_refuses_what_it_cannot_do(assets):
+    """Error behaviour of the per-env slot calls: index errors for slots that do not exist, value errors for tables that
+    cannot serve -- never a silent fallback."""
+    import torch
+    from red_gym_amd import F110VecEnv, _lib
+    from red_gym_amd.engine import DEFAULT_PARAMS, Engine, params_vec
+    with pytest.raises(ValueError):
+        Engine(num_envs=100, seed=list(range(100)))                       # 100 distinct seeds > 64 noise slots
+    with pytest.raises(ValueError):
+        Engine(num_envs=4, seed=[1, 2, 3])                                # one seed per env
+    with pytest.raises(ValueError):
+        Engine(num_envs=4, params=[dict(DEFAULT_PARAMS)] * 3)             # one params dict per env
+    e = _engine(assets, num_envs=4, seed=[7, 8, 7, 8])
+    lib, h = e.lib, e._h
+    v = params_vec(DEFAULT_PARAMS)
+    P = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    assert lib.f110_set_params_slot(h, 4, P(v), -1) == _lib.E_INDEX       # slots 0 .. num_envs-1
+    assert lib.f110_set_params_slot(h, 1, P(v), 1) == _lib.E_INDEX        # agent 1 of a one-agent handle
+    bad = v.copy(); bad[3] = np.nan
+    assert lib.f110_set_params_slot(h, 1, P(bad), -1) == _lib.E_INVALID
+    assert lib.f110_set_params_slots(h, P(np.tile(v, 5)), 5) == _lib.E_INDEX
+    assert lib.f110_set_params_slot(h, 2, P(v), -1) == 0                  # slots 1, 2 now exist (copies of slot 0, then set)
+    assign = np.array([0, 1, 2, 3], dtype=np.int32)
+    assert lib.f110_assign_params(h, P(assign)) == _lib.E_INDEX           # slot 3 does not
+    assign[3] = 2
+    assert lib.f110_assign_params(h, P(assign)) == 0
+    na = np.array([0, 1, 2, 0], dtype=np.int32)
+    assert lib.f110_assign_noise(h, P(na)) == _lib.E_INDEX                # two noise slots only
+    assert lib.f110_noise_set_floor(h, 10 ** 6, None) == _lib.E_INVALID   # above the rows produced
+    assert lib.f110_pack_env(h, 4, C.c_void_p(e.t['state'].data_ptr()), None) in (_lib.E_INDEX, _lib.E_UNBOUND)
+    out = np.empty((2, 1080))
+    assert lib.f110_noise_read(h, 0, 10 ** 6, 2, P(out)) == _lib.E_INDEX  # rows that are not in the table
+    assert b'noise_read' in lib.f110_last_error()
+    e.close()
+    # a host table that is too short is an error at f110_noise_ensure, not a wrap-around
+    e = _engine(assets, num_envs=1, noise_source='numpy')
+    with torch.cuda.device(e.device):
+        assert e.lib.f110_noise_ensure(e._h, 10 ** 6, None) == _lib.E_INVALID
+        assert e.lib.f110_noise_set_floor(e._h, 1, None) == _lib.E_INVALID    # rows are only dropped from generated noise
+    e.close()
