@@ -1,7 +1,8 @@
 """Domain randomisation on one GPU: K random tracks (the reference's unittest/random_trackgen.py walker, drawn and
-turned into maps on the device), the envs split over them, a GPU pure-pursuit policy per block, and the bird's-eye
-bitmap the reference's RL consumers build from every scan (weap_util.lidar.lidar_to_bitmap) -- nothing leaves the
-GPU inside the loop.
+turned into maps on the device), the envs split over them, EVERY env with its own vehicle (friction, cornering stiffness,
+mass, inertia: the `params` a reference env is constructed with, f110_env.py:125-128) and one of 32 lidar-noise seeds
+(:102-105), a GPU pure-pursuit policy per block, and the bird's-eye bitmap the reference's RL consumers build from every scan
+(weap_util.lidar.lidar_to_bitmap) -- nothing leaves the GPU inside the loop.
 
     python examples/random_tracks.py [--envs 8192] [--tracks 8] [--steps 500]
 """
@@ -15,6 +16,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 from red_gym_amd import F110VecEnv, LidarBitmap, workload  # noqa: E402
+from red_gym_amd.engine import DEFAULT_PARAMS  # noqa: E402
 
 
 def main():
@@ -24,7 +26,11 @@ def main():
     ap.add_argument('--steps', type=int, default=500)
     ap.add_argument('--seed', type=int, default=2025)
     a = ap.parse_args()
-    env = F110VecEnv(a.envs, map=workload.EXAMPLE_MAP, num_agents=1, autoreset=False)
+    rng = np.random.default_rng(a.seed)
+    vehicles = [dict(DEFAULT_PARAMS, mu=float(rng.uniform(0.8, 1.2)), C_Sf=float(rng.uniform(4.0, 5.4)), C_Sr=float(rng.uniform(4.6, 6.2)),
+                     m=float(rng.uniform(3.3, 4.2)), I=float(rng.uniform(0.04, 0.055))) for _ in range(a.envs)]
+    seeds = [a.seed + e % 32 for e in range(a.envs)]
+    env = F110VecEnv(a.envs, map=workload.EXAMPLE_MAP, num_agents=1, autoreset=False, params=vehicles, seed=seeds)
     t0 = time.perf_counter()
     tracks, assign = env.randomize_tracks(range(a.seed, a.seed + a.tracks))
     torch.cuda.synchronize()
