@@ -79,6 +79,19 @@ def cpu_baseline(num_agents, budget_s=12.0):
             'single_thread_value': 64 * 6 / dt1}
 
 
+class _stdout_to_stderr(object):
+    """Gloo announces its connections on the C-level stdout; rank 0's stdout carries the ONE JSON line and nothing else."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+
+
 class Ranks(object):
     """One process per GPU (RANK / LOCAL_RANK / WORLD_SIZE from torch.distributed.run).
     The step path has no collective: ranks only meet at the barriers around the timed
@@ -122,10 +135,14 @@ class Ranks(object):
                         pass
                     self.backend = 'gloo'
                     port = int(os.environ['MASTER_PORT']) + 1      # a fresh store: the failed group may have left keys behind
-                    dist.init_process_group('gloo', init_method='tcp://%s:%d' % (os.environ['MASTER_ADDR'], port),
-                                            rank=self.rank, world_size=self.world)
+                    with _stdout_to_stderr():
+                        dist.init_process_group('gloo', init_method='tcp://%s:%d' % (os.environ['MASTER_ADDR'], port),
+                                                rank=self.rank, world_size=self.world)
+                        dist.barrier()
             else:
-                dist.init_process_group(backend, rank=self.rank, world_size=self.world)
+                with _stdout_to_stderr():
+                    dist.init_process_group(backend, rank=self.rank, world_size=self.world)
+                    dist.barrier()
 
     def _comm_device(self):
         return self.device if self.backend == 'nccl' else 'cpu'
