@@ -1539,7 +1539,7 @@ static int run_step(f110_handle *h, const double *actions, int reset_only, const
     e.lap_times = b.lap_times; e.current_time = b.current_time; e.pending_reset = b.pending_reset; e.done = b.done; e.checkpoint_done = b.checkpoint_done;
     e.time_step = c.timestep; e.params = h->d_params; e.env_params = h->multi_params ? h->d_env_params : nullptr; e.param_slots = h->param_slots; e.dev_err = h->d_err;
     const int env_blocks = (c.num_envs + 127) / 128;
-    if (c.num_agents == 1) return emit(st, (const void *)&env_kernel, dim3(env_blocks), dim3(128), 0, e);
+    if (c.num_agents == 1) return emit(st, (const void *)&env_kernel<true>, dim3(env_blocks), dim3(128), 0, e);
 
     // A > 1: env bookkeeping and the opponents' set-up side by side in one launch, then the ray cast
     PostScanArgs ps;

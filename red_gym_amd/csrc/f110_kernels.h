@@ -1125,16 +1125,22 @@ __global__ __launch_bounds__(128) void check_done_kernel(CheckDoneArgs a)
     a.done[env] = ((a.collisions[c0 + a.ego_idx] != 0) || all_done) ? 1 : 0; // :242
 }
 
+// ONE: the env has one agent (no pair to test: the GJK code is not even compiled in, the kernel is a third of the size)
+template <bool ONE>
 __device__ inline void env_body(const EnvArgs &a, int env)
 {
     if (env >= a.n_envs) return;
     const bool pend = a.pending_reset[env] != 0;
     if (a.reset_only && !pend) return;
-    const int A = a.agents, c0 = env * A;
-    // Simulator.check_collision (base_classes.py:529-543) on the post-integration poses
-    const Params &SP = a.params[(size_t)params_slot_of(a.env_params, env, a.param_slots, a.dev_err) * (A + 1)]; // Simulator.params (:542)
-    collision_multiple_dev(a.pose_snap + (size_t)c0 * 3, A, SP.v[P_LENGTH], SP.v[P_WIDTH],
-                           a.collisions + c0, a.collision_idx + c0);
+    const int A = ONE ? 1 : a.agents, c0 = env * A;
+    if (ONE) {
+        a.collisions[c0] = 0; a.collision_idx[c0] = -1; // collision_multiple (collision_models.py:185-212) on one quad
+    } else {
+        // Simulator.check_collision (base_classes.py:529-543) on the post-integration poses
+        const Params &SP = a.params[(size_t)params_slot_of(a.env_params, env, a.param_slots, a.dev_err) * (A + 1)]; // Simulator.params (:542)
+        collision_multiple_dev(a.pose_snap + (size_t)c0 * 3, A, SP.v[P_LENGTH], SP.v[P_WIDTH],
+                               a.collisions + c0, a.collision_idx + c0);
+    }
     for (int i = 0; i < A; i++) {
         if (a.in_collision[c0 + i]) {
             a.collisions[c0 + i] = 1; // :581-582
@@ -1168,7 +1174,8 @@ __device__ inline void env_body(const EnvArgs &a, int env)
     if (a.autoreset && dn) a.pending_reset[env] = 1;
 }
 
-__global__ __launch_bounds__(128) void env_kernel(EnvArgs a) { env_body(a, blockIdx.x * blockDim.x + threadIdx.x); }
+template <bool ONE>
+__global__ __launch_bounds__(128) void env_kernel(EnvArgs a) { env_body<ONE>(a, blockIdx.x * blockDim.x + threadIdx.x); }
 
 // A > 1: the env bookkeeping and the opponents' set-up in ONE launch.  Both are small kernels whose time is latency (256 and
 // 2 048 waves), and neither reads what the other writes -- except that env_body zeroes the yaw of a car whose iTTC fired, for
@@ -1182,7 +1189,7 @@ struct PostScanArgs {
 
 __global__ __launch_bounds__(128) void post_scan_kernel(PostScanArgs a)
 {
-    if ((int)blockIdx.x < a.env_blocks) env_body(a.e, blockIdx.x * blockDim.x + threadIdx.x);
+    if ((int)blockIdx.x < a.env_blocks) env_body<false>(a.e, blockIdx.x * blockDim.x + threadIdx.x);
     else opp_setup_body(a.o, (blockIdx.x - a.env_blocks) * blockDim.x + threadIdx.x);
 }
 
