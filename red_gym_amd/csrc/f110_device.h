@@ -63,8 +63,10 @@ __device__ inline void vehicle_dynamics_st(const double x[7], double sv_in, doub
         double k1 = accl_constraints(x[3], u1, p[P_VSWITCH], p[P_AMAX], p[P_VMIN], p[P_VMAX]);
         double tx2 = tan(x[2]);
         double cx2 = cos(x[2]);
-        f[0] = x[3] * cos(x[4]);
-        f[1] = x[3] * sin(x[4]);
+        double s4, c4;
+        sincos(x[4], &s4, &c4); // one argument reduction and one pair of kernels for both (the library's sin and cos each evaluate the pair)
+        f[0] = x[3] * c4;
+        f[1] = x[3] * s4;
         f[2] = k0;
         f[3] = k1;
         f[4] = x[3] / lwb * tx2;
@@ -74,8 +76,10 @@ __device__ inline void vehicle_dynamics_st(const double x[7], double sv_in, doub
         double glr_m = g * lr - u1 * h;
         double glf_p = g * lf + u1 * h;
         double ang = x[6] + x[4];
-        f[0] = x[3] * cos(ang);
-        f[1] = x[3] * sin(ang);
+        double sa, ca;
+        sincos(ang, &sa, &ca);
+        f[0] = x[3] * ca;
+        f[1] = x[3] * sa;
         f[2] = u0;
         f[3] = u1;
         f[4] = x[5];
@@ -155,7 +159,8 @@ __device__ inline void update_pose(double st[7], double sbuf[2], int &scnt, doub
 __device__ inline void get_vertices(double x, double y, double th, double length, double width,
                                     double out[4][2])
 {
-    double c = cos(th), s = sin(th);
+    double c, s;
+    sincos(th, &s, &c);
     const double hx[4] = {-length / 2, -length / 2, length / 2, length / 2};
     const double hy[4] = {width / 2, -width / 2, -width / 2, width / 2};
 #pragma unroll

@@ -753,7 +753,8 @@ __device__ inline void opp_setup_body(const OppArgs &a, int t)
     vsel(verts, c, cx, cy);
     vsel(verts, cn, nx, ny);
     // laser_models.py:283-315
-    const double ex = cos(pyaw), ey = sin(pyaw);
+    double ex, ey;
+    sincos(pyaw, &ey, &ex);
     const double ego_ang = atan2(ey, ex);
     const double vx = cx - px, vy = cy - py;
     const double norm = sqrt(vx * vx + vy * vy);
@@ -1155,7 +1156,9 @@ __device__ inline void env_body(const EnvArgs &a, int env)
         // F110Env.reset (f110_env.py:318-329)
         ct = 0.0;
         const double th = -a.spawn[(size_t)(c0 + a.ego_idx) * 3 + 2];
-        r00 = cos(th); r01 = -sin(th); r10 = sin(th); r11 = cos(th);
+        double sth, cth;
+        sincos(th, &sth, &cth);
+        r00 = cth; r01 = -sth; r10 = sth; r11 = cth;
         a.start_rot[(size_t)env * 4] = r00; a.start_rot[(size_t)env * 4 + 1] = r01;
         a.start_rot[(size_t)env * 4 + 2] = r10; a.start_rot[(size_t)env * 4 + 3] = r11;
         for (int i = 0; i < A; i++) { a.near_start[c0 + i] = 1; a.toggles[c0 + i] = 0; }
