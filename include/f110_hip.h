@@ -207,8 +207,11 @@ int f110_edt_squared_dev(const uint8_t *free_mask_dev, int32_t height, int32_t w
  * lets the table recycle them -- it is a ring, so a run of any length holds a window of rows in constant memory.
  * Lowering the floor again (a reset) re-produces the dropped rows from the seeds.  A car whose row lies outside
  * [floor, rows produced) sets F110_DEVERR_NOISE_WINDOW in the device error word instead of reading silently.
- * The table's address reaches the kernels through a device-resident descriptor: growth never invalidates a captured
- * hipGraph (the launch epoch does not move). */
+ * Launch epoch: the scan takes the table's base and size by value (a pointer chase per wave costs 0.9 % of the launch), so
+ * a RE-ALLOCATION -- the ring too small for the rows between the floor and the fastest car: it doubles -- moves the launch
+ * epoch like every other table change; the window of rows present (floor, rows produced) moves without it, behind a
+ * device-resident descriptor.  A run whose floor follows its cars never re-allocates: one captured hipGraph serves it
+ * for any length (tests/test_gpu_noise.py: 20 000 replays). */
 int f110_set_noise_table(f110_handle *h, const double *table_host, int64_t T);
 int f110_set_noise_slot(f110_handle *h, int32_t slot, const double *table_host, int64_t T);
 int f110_set_noise_generator(f110_handle *h, int32_t slot, const uint64_t *pcg64_state_inc, double std_dev);
@@ -260,8 +263,8 @@ int f110_set_scan_stages(f110_handle *h, const char *spec);
 
 /* hipGraph support.  f110_step only enqueues kernels (no allocation, no synchronisation), so it can be captured
  * into a HIP graph and replayed.  A capture freezes the kernel selection and the by-value launch arguments; the
- * calls that change them -- f110_bind, f110_set_tables, f110_set_noise_table (the table is re-allocated), every map
- * install, f110_assign_maps -- bump the handle's launch epoch.  A graph captured at epoch e is valid while
+ * calls that change them -- f110_bind, f110_set_tables, every map install, f110_assign_maps / _params / _noise, a
+ * re-allocation of the noise table -- bump the handle's launch epoch.  A graph captured at epoch e is valid while
  * f110_launch_epoch still reports e; after that it must be re-captured (F110VecEnv.step_graph does so itself). */
 int f110_launch_epoch(f110_handle *h, int64_t *epoch);
 

@@ -919,6 +919,7 @@ static int noise_resize(f110_handle *h, int slots, long long cap)
     h->d_noise = nt;
     h->noise_cap = cap;
     h->noise_slots = slots;
+    h->epoch++; // the scan takes the table's base and size by value (ScanArgs::noise_base): a re-allocation is a new launch
     return noise_publish(h, nullptr);
 }
 
@@ -1386,7 +1387,7 @@ static int check_scan_args(const ScanArgs &a, const char *who)
     if (a.n_cars < 1 || a.agents < 1 || a.scan.nb < 2 || a.scan.nb > MAX_CHUNKS * 64) return fail(F110_E_INVALID, "%s: %d cars, %d agents, %d beams", who, a.n_cars, a.agents, a.scan.nb);
     if (!a.maps || !a.scan.cs || a.scan.cs_len < a.scan.theta_dis || !a.chunk_beam0 || !a.pose_src) return fail(F110_E_INVALID, "%s: a table of the scan is missing (maps / {cos,sin} LUT / chunk order / poses)", who);
     if (!a.out_f32 && !a.out_f64) return fail(F110_E_INVALID, "%s: no output buffer", who);
-    if (a.state && (!a.noise_step || !a.noise || !a.beam_cosines || !a.in_collision || !a.pending_reset))
+    if (a.state && (!a.noise_step || !a.noise_base || a.noise_cap < 1 || !a.beam_cosines || !a.in_collision || !a.pending_reset))
         return fail(F110_E_INVALID, "%s: a buffer of the step's scan is missing (noise / beam cosines / in_collision / pending_reset)", who);
     if (!a.state && a.reset_only) return fail(F110_E_INVALID, "%s: reset_only without the step's buffers", who);
     return F110_OK;
@@ -1467,7 +1468,8 @@ static void fill_scan_args(const f110_handle *h, ScanArgs &s, int reset_only)
     s.maps = h->d_maps; s.env_map = h->multi ? h->d_env_map : nullptr; s.scan = scan_dev(h); s.n_cars = c.num_envs * c.num_agents; s.agents = c.num_agents;
     s.pose_src = b.state; s.pose_stride = 7; s.yaw_off = 4;
     s.state = b.state; s.noise_step = b.noise_step; s.chunk_beam0 = h->d_chunk0;
-    s.noise = h->d_noise_desc; s.env_noise = h->multi_noise ? h->d_env_noise : nullptr; s.dev_err = h->d_err;
+    s.noise_base = h->d_noise; s.noise_cap = (int)h->noise_cap; s.noise_mask = (int)(h->noise_cap - 1); s.noise_slots = h->noise_slots;
+    s.env_noise = h->multi_noise ? h->d_env_noise : nullptr; s.dev_err = h->d_err;
     s.beam_cosines = h->d_beam_cosines; s.ttc_thresh = c.ttc_thresh;
     s.in_collision = b.in_collision; s.pending_reset = b.pending_reset; s.reset_only = reset_only;
     s.out_f32 = b.scans; s.out_f64 = b.scans_f64; s.lookups = b.lookups;
@@ -1499,7 +1501,7 @@ static int run_step(f110_handle *h, const double *actions, int reset_only, const
         DynArgs d;
         d.n_cars = N; d.agents = c.num_agents; d.state = b.state; d.steer_buf = b.steer_buf; d.steer_cnt = b.steer_cnt;
         d.noise_step = b.noise_step; d.actions = actions; d.spawn = b.spawn; d.pending_reset = b.pending_reset;
-        d.was_pending = h->d_was_pending; d.reset_only = reset_only; d.pose_snap = b.pose_snap; d.in_collision = b.in_collision; d.params = h->d_params; d.env_params = h->multi_params ? h->d_env_params : nullptr; d.param_slots = h->param_slots; d.dev_err = h->d_err;
+        d.was_pending = h->d_was_pending; d.reset_only = reset_only; d.pose_snap = b.pose_snap; d.in_collision = b.in_collision; d.params = h->d_params; d.env_params = h->multi_params ? h->d_env_params : nullptr; d.param_slots = h->param_slots; d.dev_err = h->d_err; d.noise = h->d_noise_desc;
         d.time_step = c.timestep; d.integrator = c.integrator;
         if ((rc = emit(st, (const void *)&dynamics_kernel, dim3((N + 255) / 256), dim3(256), 0, d))) return rc;
     }

@@ -275,8 +275,14 @@ struct ScanArgs {
     // full-step extras (all NULL for the function-level scan)
     const double *state;         // [N,7]: velocity for the iTTC test
     const int32_t *noise_step;   // [N]
-    const NoiseDesc *noise;      // device descriptor of the noise table ({noise of a row, side distance} pairs: one 16-B gather
-                                 // per beam taken); read once per car, its address is fixed for the handle's life
+    // The noise table ({noise of a row, side distance} pairs: one 16-B gather per beam taken): [noise_slots][noise_cap][nb], a
+    // ring of noise_cap = noise_mask + 1 rows per slot.  Base and size travel BY VALUE -- through the device-resident
+    // descriptor every wave started with a chain of two dependent scalar loads, 0.9 % of the launch (profiles/r04_noise.txt)
+    // -- so they only change when the table is re-allocated (f110_launch_epoch moves then; a ring that follows the cars
+    // never is).  The window of rows that are present moves all the time: it stays behind the descriptor and is checked
+    // by dynamics_kernel, off this kernel's path.
+    const double2 *noise_base;
+    int noise_mask, noise_cap, noise_slots;
     const int32_t *env_noise;    // [B] noise slot (= seed) of every env, or NULL (all envs on slot 0)
     uint32_t *dev_err;           // device error word (f110_device_errors): F110_DEVERR_* bits, or NULL
     const double *beam_cosines;  // [nb]
@@ -333,14 +339,11 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
     const int nb = a.scan.nb;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int wid = blockIdx.x * SCAN_WAVES + wave; // wave-uniform (scalar)
-    // the noise table's descriptor: a pointer chase (kernarg -> descriptor), started here so that it completes behind the
-    // staging of the LUT instead of at the head of the car's first refill
-    NoiseDesc nd;
-    if (STEP) nd = *rare->noise;
     // wave -> (car, part of its beam queue).  Kept to one extra argument and shifts: this kernel sits at
     // the 80-SGPR budget of 8 waves/SIMD, and a scalar spilled inside the refill loop costs ~3 % of the launch.
-    int wpc, car, part;
+    int wpc, car, part, lg; // (wpc = 2^lg: the divisions by it below are shifts -- a scalar integer division is ~25 dependent instructions)
     {
+        // (the stage list read from the kernel arguments with constant indices instead -- no dependent loads -- measured no better)
         int t = wid, c = 0, st = 0;
         const int ns = rare->n_stages;
         for (; st < ns; st++) {
@@ -348,13 +351,14 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
             if (t < w) break;
             t -= w; c += cars_s;
         }
-        const int lg = st < ns ? rare->stage_log2w[st] : 0;
+        lg = st < ns ? rare->stage_log2w[st] : 0;
         wpc = 1 << lg; car = st < ns ? c + (t >> lg) : a.n_cars; part = t & (wpc - 1);
     }
     // the car's map (wave-uniform: scalar loads); waves past the last car still help to stage the LUT
     const int car_c = rare->car_base + min(car, a.n_cars - 1);
+    const int env_c = a.agents == 1 ? car_c : car_c / a.agents; // (one agent: no division at run time)
     F110_BCHK(rare->n_stages >= 1 && rare->n_stages <= SCAN_MAX_STAGES, BT_STAGE_LIST, rare->dev_err);
-    int map_slot = a.env_map ? a.env_map[car_c / a.agents] : 0;
+    int map_slot = a.env_map ? a.env_map[env_c] : 0;
 #if defined(F110_BOUNDS)
     F110_BCHK((unsigned)map_slot < 64u /* F110_MAX_MAPS */, BT_MAP_SLOT, rare->dev_err);
     if ((unsigned)map_slot >= 64u) map_slot = 0;
@@ -378,10 +382,10 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
     car += rare->car_base; // (from here on the car's index in the shard)
     // this wave's slice of the car's beam queue: chunk positions part, part+wpc, ...
     const int nch = (nb + 63) >> 6;
-    const int my_chunks = nch > part ? (nch - part + wpc - 1) / wpc : 0;
-    const int owns_last = my_chunks > 0 && ((nch - 1) % wpc) == part;
+    const int my_chunks = nch > part ? (nch - part + wpc - 1) >> lg : 0;
+    const int owns_last = my_chunks > 0 && ((nch - 1) & (wpc - 1)) == part;
     const int nbl = my_chunks * 64 - (owns_last ? nch * 64 - nb : 0); // beams of this wave
-    if (a.reset_only && !a.pending_reset[car / a.agents]) return;
+    if (a.reset_only && !a.pending_reset[env_c]) return; // (car == car_c here: the waves past the last car have left)
 
     const double px = a.pose_src[(size_t)car * a.pose_stride];
     const double py = a.pose_src[(size_t)car * a.pose_stride + 1];
@@ -396,19 +400,14 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
     const double cand = a.ttc_thresh * fabs(vel) * 1.000000001;
     const double2 *__restrict__ ns = nullptr;
     if (STEP) {
-        // the car's noise row: row `scans since its reset` of its env's slot (a ring of nd.cap rows per slot)
+        // the car's noise row: row `scans since its reset` of its env's slot (a ring of noise_cap rows per slot)
         const int row = a.noise_step[car];
-        const int32_t *en = rare->env_noise;
-        int slot = en ? en[car / a.agents] : 0;
+        int slot = a.env_noise ? a.env_noise[env_c] : 0;
 #if defined(F110_BOUNDS)
-        F110_BCHK(slot >= 0 && slot < nd.slots, BT_NOISE_SLOT, rare->dev_err);
-        if (!(slot >= 0 && slot < nd.slots)) slot = 0;
+        F110_BCHK(slot >= 0 && slot < rare->noise_slots, BT_NOISE_SLOT, rare->dev_err);
+        if (!(slot >= 0 && slot < rare->noise_slots)) slot = 0;
 #endif
-        if (__builtin_expect(row < nd.lo || row >= nd.hi, 0)) {
-            // the host keeps the table ahead of every car (Engine._ensure_noise); a row outside it is reported, never silent
-            if (lane == 0 && rare->dev_err) atomicOr(rare->dev_err, DEVERR_NOISE_WINDOW);
-        }
-        ns = nd.base + (size_t)(unsigned)(slot * nd.cap + (row & nd.mask)) * (size_t)(unsigned)nb; // (slots * cap rows < 2^31: noise_resize)
+        ns = a.noise_base + (size_t)(unsigned)(slot * a.noise_cap + (row & a.noise_mask)) * (size_t)(unsigned)nb; // (slots * cap rows < 2^31: noise_resize)
     }
     float *o32 = a.out_f32 ? a.out_f32 + (size_t)car * nb : nullptr;
     double *o64 = a.out_f64 ? a.out_f64 + (size_t)car * nb : nullptr;
@@ -933,8 +932,9 @@ struct DynArgs {
     const int32_t *env_params;  // [B] params slot of every env, or NULL (all envs on slot 0)
     double time_step;
     int integrator;
-    int param_slots;            // slots `params` holds   \ read by the bounds-checked build only
-    uint32_t *dev_err;          // device error word      /
+    int param_slots;            // slots `params` holds (read by the bounds-checked build only)
+    uint32_t *dev_err;          // device error word
+    const NoiseDesc *noise;     // the rows the noise table holds (or NULL): the scan behind this kernel reads row noise_step[car] unchecked
 };
 
 // The single-track model switches to its kinematic form below 0.5 m/s (dynamic_models.py:152): a wavefront that holds
@@ -1011,6 +1011,12 @@ __global__ __launch_bounds__(256) void dynamics_kernel(DynArgs a)
     a.steer_buf[(size_t)car * 2 + 1] = sb[1];
     a.steer_cnt[car] = sc;
     if (a.in_collision) a.in_collision[car] = 0;
+    if (a.noise && a.noise_step) {
+        // the host keeps the noise table ahead of every car (Engine._ensure_noise); a row outside it is reported, never silent
+        const int row = pend ? 0 : a.noise_step[car];
+        if (__builtin_expect(row < a.noise->lo || row >= a.noise->hi, 0))
+            if (a.dev_err) atomicOr(a.dev_err, DEVERR_NOISE_WINDOW);
+    }
     if (a.pose_snap) {
         a.pose_snap[(size_t)car * 3] = st[0];
         a.pose_snap[(size_t)car * 3 + 1] = st[1];

@@ -159,15 +159,9 @@ class Engine(object):
         if self._noise_on:
             self._setup_noise(env_seeds if env_seeds is not None else [seed], float(noise_std))
         self._alloc(keep_f64_scans, count_lookups)
-        if self._noise_on:
+        if self._noise_on and noise_steps:
             with torch.cuda.device(self.device):
-                if noise_steps:
-                    self._noise_to(int(noise_steps))
-                elif self._noise_gen:
-                    # the first chunk of rows is produced on the library's own stream while the caller installs the map and
-                    # uploads poses; the first reset only waits for it
-                    _lib.check(self.lib.f110_noise_prefetch(self._h, 2 + self.NOISE_CHUNK))
-                    self._noise_prefetched = True
+                self._noise_to(int(noise_steps))
 
     # ------------------------------------------------------------------ buffers
     def _alloc(self, keep_f64, count_lookups):

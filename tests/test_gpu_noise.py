@@ -186,7 +186,8 @@ def test_long_run_is_a_ring_of_constant_size(assets):
 
 def test_autoreset_keeps_every_row_and_grows_quietly(assets):
     """autoreset on: a car may be sent back to row 0 at any step, so rows are never dropped; a car that outlives the table
-    makes it double (1 024 -> 2 048) without moving the launch epoch, and a captured graph keeps replaying."""
+    makes it double (1 024 -> 2 048 rows).  The re-allocation is the one event that moves the launch epoch (the scan takes
+    the table's base by value): a captured graph is re-captured by step_graph and keeps giving the eager results."""
     import torch
     from red_gym_amd import F110VecEnv
     B = 2
@@ -202,7 +203,7 @@ def test_autoreset_keeps_every_row_and_grows_quietly(assets):
         e1.step_graph(); e2.step(z)
         if k % 100 == 99 or k > 1015:
             assert torch.allclose(e1.eng.t['scans_f64'], e2.eng.t['scans_f64'], rtol=0, atol=2e-17), k
-    assert e1.eng.launch_epoch() == ep0 and e1.eng.noise_info()[0] == 0 and e1.eng.noise_info()[2] == 2048
+    assert e1.eng.launch_epoch() == ep0 + 1 and e1.eng.noise_info()[0] == 0 and e1.eng.noise_info()[2] == 2048
     assert e1.eng.device_errors() == 0 and e2.eng.device_errors() == 0
     e1.close(); e2.close()
 

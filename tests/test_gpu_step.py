@@ -321,11 +321,11 @@ def test_library_graph_replay_equals_eager(assets, how, A):
 
 
 def test_hipgraph_survives_table_changes(assets):
-    """A captured step freezes the scan instantiation and the env -> map table.  The noise table is NOT part of that
-    any more: the kernels reach it through a device-resident descriptor, so re-allocating it when a car outlives it
-    (here: a host table of 64 rows that a 71-scan run outgrows) leaves the launch epoch and the captured graph alone.
-    update_map can switch the instantiation (berlin: resolution 0.05, not a power of two): step_graph must notice
-    (launch epoch) and re-capture instead of replaying against freed memory.  Scans, state, noise rows `==` eager."""
+    """A captured step freezes the scan instantiation, the env -> map table and the noise table's base and size.  The
+    noise table is re-allocated when a car outlives it (here: a host table of 64 rows that a 71-scan run outgrows), and
+    update_map can switch the instantiation (berlin: resolution 0.05, not a power of two): step_graph must notice (launch
+    epoch) and re-capture instead of replaying against freed memory.  Scans, state, noise rows `==` eager stepping.
+    (The WINDOW of rows a table holds moves without touching the epoch: test_gpu_noise.py, 20 000 replays of one graph.)"""
     import torch
     from red_gym_amd import workload
     B = 64
@@ -341,7 +341,7 @@ def test_hipgraph_survives_table_changes(assets):
         buf.copy_(acts[k % 8])
         e2.step_graph()
         assert torch.equal(e1.eng.t['scans_f64'], e2.eng.t['scans_f64']), k
-    assert e2.eng._noise_rows > rows0 and e2.eng.launch_epoch() == ep0   # re-allocated, and the graph was not re-captured
+    assert e2.eng._noise_rows > rows0 and e2.eng.launch_epoch() > ep0    # re-allocated: the graph was re-captured
     assert torch.equal(e1.state, e2.state) and int(e2.eng.t['noise_step'].min()) >= 30
     # another map with another scan instantiation, then back
     for y in (os.path.join(assets, 'maps', 'berlin.yaml'), os.path.join(assets, 'example_map.yaml')):
