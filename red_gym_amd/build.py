@@ -2,14 +2,14 @@
     python -m red_gym_amd.build
 hipcc cross-compiles without a GPU; the resulting libf110_hip.so is git-ignored
 but travels with the tree to the GPU box."""
+import glob
 import os
 import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, 'csrc', 'f110_abi.hip')
-DEPS = [SRC, os.path.join(HERE, 'csrc', 'f110_kernels.h'), os.path.join(HERE, 'csrc', 'f110_device.h'), os.path.join(HERE, 'csrc', 'f110_bitmap.h'), os.path.join(HERE, 'csrc', 'f110_mapgen.h'), os.path.join(HERE, 'csrc', 'f110_planner.h'),
-        os.path.join(os.path.dirname(HERE), 'include', 'f110_hip.h')]
+DEPS = [SRC] + sorted(glob.glob(os.path.join(HERE, 'csrc', '*.h'))) + [os.path.join(os.path.dirname(HERE), 'include', 'f110_hip.h')]
 LIB = os.path.join(HERE, 'libf110_hip.so')
 
 # -ffp-contract=off: the reference's cell / LUT indices and collision decisions are
