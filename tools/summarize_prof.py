@@ -5,6 +5,12 @@ import os
 import sys
 from collections import defaultdict
 
+
+def is_scan(name):
+    """f110::scan_kernel<...> only (post_scan_kernel, the env / opponent set-up launch of A > 1, also carries the words)"""
+    return 'scan_kernel' in name and 'post_scan_kernel' not in name
+
+
 out = sys.argv[1]
 
 
@@ -25,7 +31,7 @@ for label, pat in (('bench.py', 'stats/**/*kernel_stats.csv'), ('tools/bench_bit
 # the bench's own events bracket the K TIMED launches only; the stats above average every launch of the process
 # (spin-up, reset, warm-up too), so the same K dispatches are averaged from the trace for comparison
 for f in find('stats/**/*kernel_trace.csv'):
-    rows = [r for r in csv.DictReader(open(f)) if 'scan_kernel' in r['Kernel_Name']]
+    rows = [r for r in csv.DictReader(open(f)) if is_scan(r['Kernel_Name'])]
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
     d = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3 for r in rows]
     K = 20
@@ -44,7 +50,7 @@ print('== PMC counters: mean per dispatch of scan_kernel (bmwrite: of bitmap_ker
 for f in find('pmc_*/**/*counter_collection.csv'):
     acc, cnt = defaultdict(float), defaultdict(int)
     for row in csv.DictReader(open(f)):
-        if ('bitmap_kernel' if 'bmwrite' in f else 'scan_kernel') not in row['Kernel_Name']:
+        if not (('bitmap_kernel' in row['Kernel_Name']) if 'bmwrite' in f else is_scan(row['Kernel_Name'])):
             continue
         acc[row['Counter_Name']] += float(row['Counter_Value'])
         cnt[row['Counter_Name']] += 1

@@ -7,6 +7,12 @@ import json
 import os
 import sys
 
+
+def is_scan(name):
+    """f110::scan_kernel<...> only (post_scan_kernel, the env / opponent set-up launch of A > 1, also carries the words)"""
+    return 'scan_kernel' in name and 'post_scan_kernel' not in name
+
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 prof, key, summary = sys.argv[1], sys.argv[2], sys.argv[3]
 val = {}
@@ -14,7 +20,7 @@ for name in ('fetch', 'write'):
     acc = cnt = 0
     for f in glob.glob(os.path.join(prof, 'pmc_%s' % name, '**', '*counter_collection.csv'), recursive=True):
         for row in csv.DictReader(open(f)):
-            if 'scan_kernel' in row['Kernel_Name']:
+            if is_scan(row['Kernel_Name']):
                 acc += float(row['Counter_Value']); cnt += 1
     val[name] = acc / max(cnt, 1)
 tj_path = os.path.join(ROOT, 'profiles', 'traffic.json')
