@@ -86,7 +86,20 @@ if w1.sum() > 100:
     cp = np.corrcoef(life[w1], prev_lookups[car[w1]])[0, 1]
     print('  whole-car waves: correlation of lifetime with the car\'s lookups %.3f (this step), %.3f (previous step); lookups per car p50/p99/max %d %d %d'
           % (cc, cp, np.percentile(lookups, 50), np.percentile(lookups, 99), lookups.max()))
+# workgroups of the classic launch hold SCAN_WAVES = 2 consecutive waves: a slot whose wave is done waits for the workgroup's other
+# wave before the workgroup's LDS is free for the next one
+if os.environ.get('F110_SCAN_WAVES', '2') == '2':
+    part = (buf[:, 3] & np.uint64(0xff)).astype(np.int64)
+    key = np.where(wpc == 1, car // 2, -1 - (car * 8 + part // 2))  # whole cars: cars 2k, 2k+1; split cars: parts 2j, 2j+1 of a car
+    o = np.argsort(key, kind='stable')
+    ks, es, ss = key[o], end[o], start[o]
+    same = ks[1:] == ks[:-1]
+    i0 = np.nonzero(same)[0]
+    spread = np.abs(es[i0] - es[i0 + 1])
+    life2 = np.maximum(es[i0], es[i0 + 1]) - np.minimum(ss[i0], ss[i0 + 1])
+    print('  workgroups (%d pairs of waves): |end - end| p10/50/90 %s us; a slot waits for its workgroup\'s other wave %.1f %% of the pairs\' slot-time'
+          % (len(i0), ' '.join('%.1f' % v for v in np.percentile(spread, [10, 50, 90])), 100.0 * spread.sum() / (2.0 * life2.sum())))
 grid = np.arange(0.0, end.max() + 5.0, 5.0)
 res = [(int(((start <= t) & (end > t)).sum())) for t in grid]
-print('  resident waves every 5 us: ' + ' '.join(str(r) for r in res))
+print('  resident waves every 5 us (mean over the middle half of the launch %.0f): ' % np.mean(res[len(res) // 4: 3 * len(res) // 4]) + ' '.join(str(r) for r in res))
 env.close()
