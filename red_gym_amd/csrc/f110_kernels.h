@@ -72,7 +72,10 @@ constexpr int REFILL_MIN_IDLE = F110_REFILL_MIN_IDLE; // refill the wave's beam 
 // points, so a gather touches fewer lines than with a row-major table (which measured
 // ~40 L1 accesses per 64-lane gather and made the kernel L1-tag-rate bound), and the byte
 // offset is two shift-adds and one multiply-add: (c >> 3) * (strip_bytes - 16) + (c << 1) + (r << 4) + strip_bytes + 16.
-constexpr int LUT_LDS = 1024;                           // LDS LUT slots
+#ifndef F110_LUT_LDS
+#define F110_LUT_LDS 1024
+#endif
+constexpr int LUT_LDS = F110_LUT_LDS;                   // LDS LUT slots
 constexpr unsigned SLOT_FAR = LUT_LDS - 2, SLOT_BORDER = LUT_LDS - 1;
 constexpr unsigned OFF_FAR = 8 * SLOT_FAR, OFF_BORDER = 8 * SLOT_BORDER;
 constexpr unsigned CODE_ESC = 65535;                    // second table: read the fp64 table instead
