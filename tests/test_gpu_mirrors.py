@@ -23,6 +23,22 @@ def test_waypoint_follow_example_config1():
     assert obs['lap_counts'][0] == 2 and obs['collisions'][0] == 0
 
 
+def test_lidar_example_images_match_oracle():
+    """examples/lidar_example.py = the reference's examples/lidar_example.py:76-107 without its windows: the two images it draws
+    from every ego scan (RAYS, 50 beams, black, 3 channels, fov 4.7; FILL, white, 3 channels) through the same
+    `from weap_util.lidar import lidar_to_bitmap` call, against the oracle's rasteriser on the scans the loop produced."""
+    from oracle import bitmap as ob
+    sys.path.insert(0, os.path.join(ROOT, 'examples'))
+    import lidar_example
+    scans, blinded, nonblinded, done = lidar_example.main(steps=120, keep=10)
+    assert not done and scans.shape == (12, 1080) and blinded.shape == nonblinded.shape == (12, 256, 256, 3)
+    assert blinded.dtype == nonblinded.dtype == np.uint8
+    want_b = ob.lidar_to_bitmap(scans, channels=3, fov=lidar_example.FOV, target_beam_count=50, draw_mode='RAYS', bg_color='black')
+    want_f = ob.lidar_to_bitmap(scans, channels=3, fov=lidar_example.FOV, draw_mode='FILL', bg_color='white')
+    assert np.array_equal(blinded, want_b) and np.array_equal(nonblinded, want_f)
+    assert (nonblinded != 255).any() and (blinded != 0).any()   # something was drawn
+
+
 def test_scan_simulator_mirror(assets, golden):
     from f110_gym.envs.laser_models import ScanSimulator2D
     g = golden('g1_scan.npz')
