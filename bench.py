@@ -466,8 +466,9 @@ def main(argv=None):
                     'model': 'SURVEY 8(d) algorithmic bytes: lookups*4 + cars*(1080*4 + 72), not HBM traffic',
                     'traffic_gbs': (traffic / avg_s / 1e9) if traffic else None,
                     'traffic_frac': (traffic / avg_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                    'limiter': 'VALU issue (~81 % of SIMD slots busy) and L1->L2 gather traffic (~10 TB/s of '
-                               'TCP->TCC reads); see DESIGN.md 5 and profiles/r02*'}
+                    'limiter': 'VALU issue (~85 % of SIMD slots busy) and the L1 address / tag path (381 M accesses per '
+                               '65 536-car launch, every memory instruction takes its turn there); not HBM; see DESIGN.md 5 '
+                               'and profiles/r04_scan_stores.txt'}
         out = {'metric': 'env steps/sec (all envs), 1080-beam lidar', 'value': value, 'unit': 'env-steps/s',
                'n_gpus': world, 'steps': K, 'warmup': W, 'spinup_steps': args.spinup, 'ms_per_step': elapsed / K * 1e3,
                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
