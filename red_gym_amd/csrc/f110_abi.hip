@@ -1458,7 +1458,11 @@ static int launch_scan(f110_handle *h, const ScanArgs &a_in, const Sink &st, hip
 #if defined(F110_TIMELINE)
     a.timeline = timeline_buffer();
 #endif
-    return a.state ? launch_scan_t<1>(kind, a, st, ev0, ev1) : launch_scan_t<0>(kind, a, st, ev0, ev1);
+    // the step's scan with streaming stores, except in very large launches (profiles/r04_scan_stores.txt L);
+    // F110_SCAN_STORES=plain|stream overrides (A/B runs)
+    static const char *stores_env = getenv("F110_SCAN_STORES");
+    const bool plain = stores_env ? strcmp(stores_env, "plain") == 0 : a.n_cars > 327680;
+    return !a.state ? launch_scan_t<0>(kind, a, st, ev0, ev1) : plain ? launch_scan_t<2>(kind, a, st, ev0, ev1) : launch_scan_t<1>(kind, a, st, ev0, ev1);
 }
 
 static void fill_scan_args(const f110_handle *h, ScanArgs &s, int reset_only)

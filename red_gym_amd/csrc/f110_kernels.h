@@ -319,7 +319,8 @@ static_assert(sizeof(((ScanArgs *)0)->stage_cars) == SCAN_MAX_STAGES * sizeof(in
               sizeof(((ScanArgs *)0)->stage_log2w) == SCAN_MAX_STAGES * sizeof(int), "stage list capacity");
 static_assert(sizeof(ScanArgs) <= 4096, "kernarg segment size");
 
-// SM 0: ScanSimulator2D.scan(pose, None); 1: the scan of a step (noise, iTTC flag; env_kernel follows).
+// SM 0: ScanSimulator2D.scan(pose, None); 1: the scan of a step (noise, iTTC flag; env_kernel follows); 2: the same with
+// ordinary instead of streaming stores for the fp32 scan (launches of more than ~300 000 cars, see emit).
 template <bool IDENT, bool POW2, int SM>
 #ifndef F110_SCAN_MIN_WAVES
 #define F110_SCAN_MIN_WAVES 8
@@ -429,7 +430,14 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
         // Streaming (non-temporal) stores: the scan is written once and read by later kernels only; as ordinary stores the
         // 27 scattered store instructions of a car took their turn in the L1 beside the table look-ups, which are what bounds
         // this kernel -- 0.683 -> 0.654 ms per 65 536 cars (profiles/r04_scan_stores.txt)
-        if (o32) __builtin_nontemporal_store((float)v, reinterpret_cast<float *>(reinterpret_cast<char *>(o32) + (size_t)((unsigned)i * 4u)));
+        // (Very large launches are the exception -- 524 288 cars: 4.78 ms with ordinary stores, 4.95 ms with streaming ones, whose
+        // partial lines reach the HBM un-merged; 65 536: 0.683 / 0.654, 262 144: 2.476 / 2.459 -- so the host picks the
+        // instantiation by the launch's size.  A run-time flag tested here costs 3.4 % of the launch.)
+        if (o32) {
+            float *q = reinterpret_cast<float *>(reinterpret_cast<char *>(o32) + (size_t)((unsigned)i * 4u));
+            if (SM == 2) *q = (float)v;
+            else __builtin_nontemporal_store((float)v, q);
+        }
         if (o64) __builtin_nontemporal_store(v, reinterpret_cast<double *>(reinterpret_cast<char *>(o64) + (size_t)((unsigned)i * 8u)));
         if (do_ttc) {
             const double sd = v - sdv;
