@@ -691,3 +691,32 @@ def test_step_path_fuzz_vs_oracle(assets, seed):
             assert np.array_equal(cix[b].astype(np.float64), oo[b]['collision_idx']), (k, b, tag)
             assert bool(dn[b]) == oo[b]['done'] and np.array_equal(tg[b].astype(np.float64), oo[b]['toggles']), (k, b, tag)
     env.close()
+
+
+def test_plain_store_instantiation_matches_streaming(assets, tmp_path):
+    """Launches of more than 327 680 cars run scan_kernel<.., 2> (ordinary instead of streaming stores for the fp32 scan,
+    profiles/r04_scan_stores.txt L), a size no test reaches: F110_SCAN_STORES=plain forces that instantiation (the variable is read
+    once per process, hence the child processes).  Same seeds, same actions: every observation of 40 steps is identical."""
+    import subprocess
+    import sys
+    script = (
+        "import sys, os, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from red_gym_amd import F110VecEnv, workload\n"
+        "env = F110VecEnv(96, map=%r, num_agents=2, autoreset=True)\n"
+        "env.reset(workload.spawn_poses(96, 2))\n"
+        "acts = torch.as_tensor(workload.action_pool(4, 96, 2), device='cuda')\n"
+        "out = []\n"
+        "for k in range(40):\n"
+        "    obs = env.step(acts[k %% 4])[0]\n"
+        "    out.append(np.concatenate([obs['scans'].double().cpu().numpy().ravel(), obs['poses_x'].cpu().numpy().ravel(), obs['collisions'].double().cpu().numpy().ravel()]))\n"
+        "np.save(sys.argv[1], np.stack(out))\n"
+        "env.close()\n" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.join(assets, 'example_map')))
+    res = {}
+    for mode in ('stream', 'plain'):
+        path = str(tmp_path / ('obs_%s.npy' % mode))
+        env = dict(os.environ, F110_SCAN_STORES=mode)
+        r = subprocess.run([sys.executable, '-c', script, path], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[mode] = np.load(path)
+    assert res['stream'].shape == res['plain'].shape and np.array_equal(res['stream'], res['plain'])
