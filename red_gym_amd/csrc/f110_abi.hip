@@ -90,9 +90,10 @@ struct f110_handle {
     int cs_len = 0;
     double2 *d_beam_cs = nullptr;     // {cos, sin}(scan_angles) for the opponent ray cast
     std::vector<double> h_sines, h_cosines;
-    // Lidar noise (f110_noise.h): [noise_slots][cap][nb] {noise, side distance} pairs, rows lo .. hi-1 present; the kernels
+    // Lidar noise (f110_noise.h): [noise_slots][cap][nb] noise rows, rows lo .. hi-1 present; the kernels
     // find it through d_noise_desc, whose address never changes
-    double2 *d_noise = nullptr;
+    double *d_noise = nullptr;        // [noise_slots][noise_cap][num_beams] noise rows (a ring per slot)
+    double side_max = 0.0;            // largest finite side distance (the scan's pre-test for iTTC candidates)
     long long noise_cap = 0, noise_lo = 0, noise_hi = 0; // cap: rows per slot (a power of two); noise off: cap 1, hi = "infinity"
     int noise_slots = 1;
     bool noise_on = false;
@@ -113,7 +114,7 @@ struct f110_handle {
     struct Retired { void *ptr; hipEvent_t ev; };
     std::vector<Retired> retired;     // old noise tables, freed once the work that may read them has drained
     uint32_t *d_err = nullptr;        // device error word (f110_device_errors)
-    std::vector<double> h_side;       // side distances (interleaved into the noise pairs)
+    std::vector<double> h_side;       // side distances (host copy of d_side)
     // Maps.  Slot 0 is "the" map of the reference's API; further slots let blocks of envs of one shard run on
     // different maps (one handle standing in for many F110Env instances with their own map each).
     struct MapSlot {
@@ -299,7 +300,6 @@ static int upload_beam_cs(f110_handle *h, const double *scan_angles)
 
 static int upload_params(f110_handle *h);
 static int noise_init(f110_handle *h);
-static int noise_side_changed(f110_handle *h);
 
 // scratch of the opponent ray cast: allocated here, never in f110_step
 static int alloc_opp_pairs(f110_handle *h)
@@ -311,6 +311,15 @@ static int alloc_opp_pairs(f110_handle *h)
     HIP_TRY(hipMalloc((void **)&h->d_was_pending, (size_t)h->cfg.num_envs));
     HIP_TRY(hipMemset(h->d_was_pending, 0, (size_t)h->cfg.num_envs));
     return F110_OK;
+}
+
+// The scan reads a beam's side distance only where the iTTC test could fire: scan value below (largest side distance +
+// the candidate margin).  Non-finite entries can never make a candidate (the reference's comparison is false for them).
+static void set_side_max(f110_handle *h)
+{
+    double m = 0.0;
+    for (double v : h->h_side) if (std::isfinite(v) && v > m) m = v;
+    h->side_max = m;
 }
 
 // (Re)builds the interleaved {cos, sin} device table from the host copies.
@@ -366,6 +375,7 @@ extern "C" int f110_create(const f110_config *cfg, f110_handle **out)
     h->h_sines = s;
     h->h_cosines = c;
     h->h_side = side;
+    set_side_max(h);
     if ((rc = upload_cs(h)) ||
         (rc = upload(&h->d_scan_angles, ang.data(), ang.size())) || (rc = upload_beam_cs(h, ang.data())) ||
         (rc = upload(&h->d_beam_cosines, bcos.data(), bcos.size())) ||
@@ -507,7 +517,7 @@ extern "C" int f110_set_tables(f110_handle *h, const double *sines, const double
     if (side) {
         if ((rc = upload(&h->d_side, side, h->cfg.num_beams))) return rc;
         h->h_side.assign(side, side + h->cfg.num_beams);
-        if ((rc = noise_side_changed(h))) return rc;
+        set_side_max(h);
     }
     return rc;
 }
@@ -899,13 +909,13 @@ static int noise_resize(f110_handle *h, int slots, long long cap)
     if ((long long)slots * cap >= 0x7fffffffll) return fail(F110_E_INVALID, "noise table: %d slots x %lld rows exceed 2^31 rows", slots, cap);
     HIP_TRY(hipDeviceSynchronize());
     noise_reap(h, true);
-    double2 *nt = nullptr;
+    double *nt = nullptr;
     const size_t total = (size_t)slots * (size_t)cap;
-    HIP_TRY(hipMalloc((void **)&nt, total * nb * sizeof(double2)));
+    HIP_TRY(hipMalloc((void **)&nt, total * nb * sizeof(double)));
     {
         const long long items = (long long)total * nb;
-        hipLaunchKernelGGL(noise_interleave_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, nullptr, (const double *)nullptr,
-                           (long long)total, nb, h->d_side, nt, 0, (long long)total, (long long)0x7fffffffffffffffll);
+        hipLaunchKernelGGL(noise_fill_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, nullptr, (const double *)nullptr,
+                           (long long)total, nb, nt, 0, (long long)total, (long long)0x7fffffffffffffffll);
     }
     if (h->d_noise && h->noise_on && h->noise_hi > h->noise_lo) {
         const int ms = std::min(slots, h->noise_slots);
@@ -935,17 +945,6 @@ static int noise_init(f110_handle *h)
     return noise_resize(h, 1, 1); // noise off: one row of zeros
 }
 
-static int noise_side_changed(f110_handle *h)
-{
-    const long long items = (long long)h->noise_slots * h->noise_cap * h->cfg.num_beams;
-    HIP_TRY(hipDeviceSynchronize());
-    hipLaunchKernelGGL(noise_set_side_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, nullptr, h->d_noise,
-                       (long long)h->noise_slots * h->noise_cap, h->cfg.num_beams, h->d_side);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipDeviceSynchronize());
-    return F110_OK;
-}
-
 // a prefetch in flight on the generator's stream becomes part of the table for work enqueued on `st` from now on
 static int noise_absorb_pending(f110_handle *h, hipStream_t st)
 {
@@ -969,7 +968,7 @@ static int noise_launch_generator(f110_handle *h, long long r1, hipStream_t st)
 {
     NoiseGenArgs g;
     g.gen = h->d_noise_gen; g.base = h->d_noise; g.mask = h->noise_cap - 1; g.cap = h->noise_cap; g.lo = h->noise_lo; g.r1 = r1;
-    g.nb = h->cfg.num_beams; g.side = h->d_side;
+    g.nb = h->cfg.num_beams;
     hipLaunchKernelGGL(noise_rows_kernel, dim3(h->noise_slots), dim3(64), 0, st, g);
     HIP_TRY(hipGetLastError());
     return F110_OK;
@@ -1021,14 +1020,14 @@ extern "C" int f110_set_noise_slot(f110_handle *h, int32_t slot, const double *t
         if (!was_on) { h->noise_lo = 0; h->noise_hi = 0; }
         if ((rc = noise_resize(h, slots, std::max(cap, (long long)2)))) return rc;
     }
-    {   // stage the rows on the device and interleave them with the side distances
+    {   // stage the rows on the device and place them in the slot's ring
         DevTemp tmp;
         double *stage = nullptr;
         HIP_TRY(tmp.alloc(&stage, (size_t)T * nb));
         HIP_TRY(hipMemcpy(stage, tbl, (size_t)T * nb * sizeof(double), hipMemcpyHostToDevice));
         const long long items = (long long)T * nb;
-        hipLaunchKernelGGL(noise_interleave_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, nullptr, (const double *)stage,
-                           (long long)T, nb, h->d_side, h->d_noise, slot, h->noise_cap, h->noise_cap - 1);
+        hipLaunchKernelGGL(noise_fill_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, nullptr, (const double *)stage,
+                           (long long)T, nb, h->d_noise, slot, h->noise_cap, h->noise_cap - 1);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipDeviceSynchronize());
     }
@@ -1158,7 +1157,7 @@ extern "C" int f110_noise_info(f110_handle *h, int64_t *lo, int64_t *hi, int64_t
     if (cap) *cap = h->noise_cap;
     if (slots) *slots = h->noise_slots;
     if (bytes) {
-        long long b = (long long)h->noise_slots * h->noise_cap * h->cfg.num_beams * (long long)sizeof(double2);
+        long long b = (long long)h->noise_slots * h->noise_cap * h->cfg.num_beams * (long long)sizeof(double);
         noise_reap(h, false);
         *bytes = b * (1 + (long long)h->retired.size());
     }
@@ -1178,12 +1177,9 @@ extern "C" int f110_noise_read(f110_handle *h, int32_t slot, int64_t row0, int64
         return fail(F110_E_INDEX, "f110_noise_read: rows %lld..%lld of slot %d; the table holds rows %lld..%lld of %d slots", (long long)row0,
                     (long long)(row0 + n_rows - 1), slot, h->noise_lo, hi - 1, h->noise_slots);
     const int nb = h->cfg.num_beams;
-    std::vector<double2> tmp((size_t)nb);
-    for (long long r = row0; r < row0 + n_rows; r++) {
-        HIP_TRY(hipMemcpy(tmp.data(), h->d_noise + ((size_t)slot * h->noise_cap + (size_t)(r & (h->noise_cap - 1))) * nb, (size_t)nb * sizeof(double2),
-                          hipMemcpyDeviceToHost));
-        for (int b = 0; b < nb; b++) out[(size_t)(r - row0) * nb + b] = tmp[b].x;
-    }
+    for (long long r = row0; r < row0 + n_rows; r++)
+        HIP_TRY(hipMemcpy(out + (size_t)(r - row0) * nb, h->d_noise + ((size_t)slot * h->noise_cap + (size_t)(r & (h->noise_cap - 1))) * nb,
+                          (size_t)nb * sizeof(double), hipMemcpyDeviceToHost));
     return F110_OK;
 }
 
@@ -1472,6 +1468,7 @@ static void fill_scan_args(const f110_handle *h, ScanArgs &s, int reset_only)
     s.maps = h->d_maps; s.env_map = h->multi ? h->d_env_map : nullptr; s.scan = scan_dev(h); s.n_cars = c.num_envs * c.num_agents; s.agents = c.num_agents;
     s.pose_src = b.state; s.pose_stride = 7; s.yaw_off = 4;
     s.state = b.state; s.noise_step = b.noise_step; s.chunk_beam0 = h->d_chunk0;
+    s.side = h->d_side; s.side_max = h->side_max;
     s.noise_base = h->d_noise; s.noise_cap = (int)h->noise_cap; s.noise_mask = (int)(h->noise_cap - 1); s.noise_slots = h->noise_slots;
     s.env_noise = h->multi_noise ? h->d_env_noise : nullptr; s.dev_err = h->d_err;
     s.beam_cosines = h->d_beam_cosines; s.ttc_thresh = c.ttc_thresh;

@@ -278,14 +278,16 @@ struct ScanArgs {
     // full-step extras (all NULL for the function-level scan)
     const double *state;         // [N,7]: velocity for the iTTC test
     const int32_t *noise_step;   // [N]
-    // The noise table ({noise of a row, side distance} pairs: one 16-B gather per beam taken): [noise_slots][noise_cap][nb], a
-    // ring of noise_cap = noise_mask + 1 rows per slot.  Base and size travel BY VALUE -- through the device-resident
+    // The noise table (one 8-B gather per beam taken): [noise_slots][noise_cap][nb], a ring of noise_cap = noise_mask + 1 rows
+    // per slot.  Base and size travel BY VALUE -- through the device-resident
     // descriptor every wave started with a chain of two dependent scalar loads, 0.9 % of the launch (profiles/r04_noise.txt)
     // -- so they only change when the table is re-allocated (f110_launch_epoch moves then; a ring that follows the cars
     // never is).  The window of rows that are present moves all the time: it stays behind the descriptor and is checked
     // by dynamics_kernel, off this kernel's path.
-    const double2 *noise_base;
+    const double *noise_base;
     int noise_mask, noise_cap, noise_slots;
+    const double *side;          // [nb] side distances (base_classes.py:123-156), read only for iTTC candidates
+    double side_max;             // their largest finite value: scan values at or above side_max + margin cannot be candidates
     const int32_t *env_noise;    // [B] noise slot (= seed) of every env, or NULL (all envs on slot 0)
     uint32_t *dev_err;           // device error word (f110_device_errors): F110_DEVERR_* bits, or NULL
     const double *beam_cosines;  // [nb]
@@ -402,7 +404,11 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
     // iTTC hit needs 0 <= (v - side)/(vel*cos) < thresh, hence |v - side| < thresh*|vel|:
     // only such candidate beams pay the exact fp64 division
     const double cand = a.ttc_thresh * fabs(vel) * 1.000000001;
-    const double2 *__restrict__ ns = nullptr;
+    // ... and only scan values below (largest side distance + cand) can be candidates at all: |v - side_i| < cand needs
+    // v < side_i + cand <= side_max + cand (the factor covers the roundings of the sum and of v - side_i), so the beam's side
+    // distance is read in that rare case only and the noise rows hold nothing but noise
+    const double side_pre = do_ttc ? (rare->side_max + cand) * 1.000000001 : -__builtin_inf(); // (no iTTC test: no value is below it)
+    const double *__restrict__ ns = nullptr;
     if (STEP) {
         // the car's noise row: row `scans since its reset` of its env's slot (a ring of noise_cap rows per slot)
         const int row = a.noise_step[car];
@@ -418,9 +424,8 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
     bool hit = false;
 
     // finishing stage of one beam: clamp (laser_models.py:143-144), noise (:450-452),
-    // stores, iTTC (:189-217).  nzv / sdv: noise and side distance of the beam, loaded by
-    // the caller ahead of time.
-    auto emit = [&](int i, double tot, double nzv, double sdv) {
+    // stores, iTTC (:189-217).  nzv: noise of the beam, loaded by the caller ahead of time.
+    auto emit = [&](int i, double tot, double nzv) {
 #if defined(F110_BOUNDS)
         F110_BCHK((unsigned)i < (unsigned)nb, BT_SCAN_STORE, rare->dev_err);
         if ((unsigned)i >= (unsigned)nb) return;
@@ -439,11 +444,11 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
             else __builtin_nontemporal_store((float)v, q);
         }
         if (o64) __builtin_nontemporal_store(v, reinterpret_cast<double *>(reinterpret_cast<char *>(o64) + (size_t)((unsigned)i * 8u)));
-        if (do_ttc) {
-            const double sd = v - sdv;
-            if (__builtin_expect(fabs(sd) < cand, 0)) {
-                const ScanArgs *ra = rare;
-                asm volatile("" : "+s"(ra)); // re-read the rarely needed arguments here instead of holding them in SGPRs
+        if (__builtin_expect(v < side_pre, 0)) {
+            const ScanArgs *ra = rare;
+            asm volatile("" : "+s"(ra)); // re-read the rarely needed arguments here instead of holding them in SGPRs
+            const double sd = v - ra->side[i];
+            if (fabs(sd) < cand) {
                 const double proj_vel = vel * ra->beam_cosines[i];
                 const double ttc = sd / proj_vel;
                 if ((ttc < ra->ttc_thresh) && (ttc >= 0.0)) hit = true;
@@ -469,8 +474,7 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
             F110_BCHK((unsigned)i < (unsigned)nb, BT_NOISE_BEAM, rare->dev_err);
             if ((unsigned)i >= (unsigned)nb) i = 0;
 #endif
-            const double2 v = STEP ? ns[i] : make_double2(0.0, 0.0);
-            emit(i, d0, v.x, v.y);
+            emit(i, d0, STEP ? ns[i] : 0.0);
         }
     } else {
         const double td = (double)a.scan.theta_dis;
@@ -487,13 +491,13 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
         bool active = false;
         int beam = -1;          // beam whose result `total` holds (-1: none)
         double x = px, y = py, c = 0, s = 0, total = 0;
-        double nz = 0, sd = 0;  // noise and side distance of the lane's beam (fetched when the beam is taken)
+        double nz = 0;          // noise of the lane's beam (fetched when the beam is taken)
         for (;;) {
             // ---- refill phase: idle lanes finish their beam and take the next one ----
             const unsigned long long idle = vote(!active);
             const int nidle = __popcll(idle);
             if (!active) {
-                // all independent loads first (one memory round trip).  The noise / side-distance entry is fetched
+                // all independent loads first (one memory round trip).  The noise entry is fetched
                 // for the beam being TAKEN and carried in registers until the beam is finished: idle lanes take
                 // consecutive beams, so this gather touches a few cache lines, where a gather by the FINISHED beams
                 // (scattered over the scan) touched a line per lane -- the L1's tag pipeline is what bounds this kernel
@@ -508,16 +512,15 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
                 F110_BCHK((unsigned)b < (unsigned)nb, BT_NOISE_BEAM, rare->dev_err);
                 if ((unsigned)b >= (unsigned)nb) b = 0;
 #endif
-                const double2 nsv = STEP ? *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(ns) + (size_t)((unsigned)b * 16u))
-                                         : make_double2(0.0, 0.0);
-                const double nzv = nz, sdv = sd;
+                const double nsv = STEP ? *reinterpret_cast<const double *>(reinterpret_cast<const char *>(ns) + (size_t)((unsigned)b * 8u)) : 0.0;
+                const double nzv = nz;
                 int ti = beam_theta_index(T0, t0w, b, a.scan);
 #if defined(F110_BOUNDS)
                 F110_BCHK((unsigned)ti < (unsigned)a.scan.cs_len, BT_CS_TABLE, rare->dev_err);
                 if ((unsigned)ti >= (unsigned)a.scan.cs_len) ti = 0;
 #endif
                 const double2 cs = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(a.scan.cs) + (size_t)((unsigned)ti * 16u)); // second round trip, overlapped with emit()
-                if (beam >= 0) emit(beam, total, nzv, sdv);
+                if (beam >= 0) emit(beam, total, nzv);
                 beam = -1;
                 if (take) {
                     c = cs.x;
@@ -526,8 +529,7 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
                     y = py + d0 * s;
                     total = d0;
                     beam = b;
-                    nz = nsv.x;
-                    sd = nsv.y;
+                    nz = nsv;
                     active = true;
                 }
             }

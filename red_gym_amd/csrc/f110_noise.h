@@ -26,10 +26,12 @@ typedef unsigned __int128 u128;
 
 // What the scan kernel needs to find a car's noise row.  Lives in device memory at an address that never changes for
 // the handle's life (the kernel's by-value arguments -- and therefore captured hipGraphs -- survive every growth).
-// Row r of slot s: base[(s * cap + (r & mask)) * num_beams + beam] = {noise, side distance of the beam}; rows lo <= r < hi
-// are present (a ring once lo > 0); noise off: cap = 1, one row of zeros.
+// Row r of slot s: base[(s * cap + (r & mask)) * num_beams + beam] = the beam's noise; rows lo <= r < hi are present (a ring once
+// lo > 0); noise off: cap = 1, one row of zeros.  (Rounds 3-4 kept {noise, side distance} pairs here so that one gather fed the
+// iTTC test as well; once the cars of a batch stand on different rows the rows stream from L2 / HBM, and the 8 redundant bytes per
+// beam cost 4.6 % of a 65 536-car launch -- the side distance is now read only for iTTC candidates, profiles/r04_scan_stores.txt M.)
 struct NoiseDesc {
-    const double2 *base;
+    const double *base;
     int mask, cap, lo, hi; // (a car's row counter is an int32: f110_buffers.noise_step)
     int slots, pad;        // slots the table holds (read by the bounds-checked build only)
 };
@@ -70,12 +72,11 @@ __device__ inline unsigned long long shfl64(unsigned long long v, int src)
 
 struct NoiseGenArgs {
     NoiseGen *gen;        // [slots]
-    double2 *base;        // the table being filled
+    double *base;         // the table being filled
     long long mask, cap;
     long long lo;         // rows below lo are generated (the stream must advance) but not stored
     long long r1;         // every active slot is brought to r1 rows
     int nb;
-    const double *side;   // [nb] side distances (interleaved with the noise, see NoiseDesc)
 };
 
 // One wavefront per noise slot (grid = slots).
@@ -92,12 +93,10 @@ __global__ __launch_bounds__(64) void noise_rows_kernel(NoiseGenArgs a)
 {
     __shared__ unsigned long long s_ki[256];
     __shared__ double s_wi[256], s_fi[256];
-    __shared__ double s_side[4096]; // the side distances that ride with the noise (num_beams <= 4096): a lone wave cannot hide a global load per window
     const int lane = threadIdx.x, slot = blockIdx.x;
     const NoiseGen g = a.gen[slot];
     if (!g.on || g.rows >= a.r1) return; // (uniform)
     for (int i = lane; i < 256; i += 64) { s_ki[i] = ZIG_KI[i]; s_wi[i] = ZIG_WI[i]; s_fi[i] = ZIG_FI[i]; }
-    for (int i = lane; i < a.nb; i += 64) s_side[i] = a.side[i];
     __syncthreads();
     const u128 M = pcg_mult(), inc = ((u128)g.inc_hi << 64) | (u128)g.inc_lo;
     // 64 steps at once: s -> A * s + C
@@ -175,7 +174,7 @@ __global__ __launch_bounds__(64) void noise_rows_kernel(NoiseGenArgs a)
             long long rw = row;
             while (gb >= nb) { gb -= nb; rw++; }
             if (rw >= a.lo)
-                a.base[((size_t)slot * (size_t)a.cap + (size_t)(rw & a.mask)) * (size_t)nb + gb] = make_double2(0.0 + std * val, s_side[gb]); // random_normal: loc + scale * x
+                a.base[((size_t)slot * (size_t)a.cap + (size_t)(rw & a.mask)) * (size_t)nb + gb] = 0.0 + std * val; // random_normal: loc + scale * x
         }
         if (last) {
             // the launch ends inside this window: the stream stands behind the candidate that produced the last beam
@@ -199,27 +198,18 @@ __global__ __launch_bounds__(64) void noise_rows_kernel(NoiseGenArgs a)
     }
 }
 
-// host-fed slot: plain fp64 rows [T, nb] (device staging copy) -> {noise, side} pairs of rows 0 .. T-1
-__global__ void noise_interleave_kernel(const double *rows, long long T, int nb, const double *side, double2 *base, int slot,
-                                        long long cap, long long mask)
+// host-fed slot: plain fp64 rows [T, nb] (device staging copy; NULL: zeros) -> rows 0 .. T-1 of the slot's ring
+__global__ void noise_fill_kernel(const double *rows, long long T, int nb, double *base, int slot, long long cap, long long mask)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= T * nb) return;
     const long long r = i / nb;
     const int b = (int)(i - r * nb);
-    base[((size_t)slot * (size_t)cap + (size_t)(r & mask)) * (size_t)nb + b] = make_double2(rows ? rows[i] : 0.0, side[b]);
-}
-
-// the side distances changed (f110_set_tables): rewrite the second component of every pair
-__global__ void noise_set_side_kernel(double2 *base, long long total_rows, int nb, const double *side)
-{
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total_rows * nb) return;
-    base[i].y = side[(int)(i % nb)];
+    base[((size_t)slot * (size_t)cap + (size_t)(r & mask)) * (size_t)nb + b] = rows ? rows[i] : 0.0;
 }
 
 // growth: rows lo .. hi-1 of every slot move to their places in a larger ring
-__global__ void noise_move_kernel(const double2 *src, long long scap, long long smask, double2 *dst, long long dcap,
+__global__ void noise_move_kernel(const double *src, long long scap, long long smask, double *dst, long long dcap,
                                   long long dmask, int slots, long long lo, long long hi, int nb)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
