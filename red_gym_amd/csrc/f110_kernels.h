@@ -405,9 +405,10 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
     // only such candidate beams pay the exact fp64 division
     const double cand = a.ttc_thresh * fabs(vel) * 1.000000001;
     // ... and only scan values below (largest side distance + cand) can be candidates at all: |v - side_i| < cand needs
-    // v < side_i + cand <= side_max + cand (the factor covers the roundings of the sum and of v - side_i), so the beam's side
+    // v < side_i + cand <= side_max + cand (the margin covers the roundings of the sum and of v - side_i), so the beam's side
     // distance is read in that rare case only and the noise rows hold nothing but noise
-    const double side_pre = do_ttc ? (rare->side_max + cand) * 1.000000001 : -__builtin_inf(); // (no iTTC test: no value is below it)
+    // (the margin is added, not multiplied in: a table of negative side distances must not pull the bound the wrong way)
+    const double side_pre = do_ttc ? (rare->side_max + cand) + 1e-9 * (fabs(rare->side_max) + cand) : -__builtin_inf(); // (no iTTC test: no value is below it)
     const double *__restrict__ ns = nullptr;
     if (STEP) {
         // the car's noise row: row `scans since its reset` of its env's slot (a ring of noise_cap rows per slot)

@@ -720,3 +720,59 @@ def test_plain_store_instantiation_matches_streaming(assets, tmp_path):
         assert r.returncode == 0, r.stderr[-2000:]
         res[mode] = np.load(path)
     assert res['stream'].shape == res['plain'].shape and np.array_equal(res['stream'], res['plain'])
+
+
+@pytest.mark.parametrize('kind', ['wide', 'mixed_sign', 'negative', 'non_finite'])
+def test_ittc_with_custom_side_tables_vs_oracle(assets, kind):
+    """The scan reads a beam's side distance only where the iTTC test can fire (scan value below the largest finite side
+    distance + the candidate margin).  Side tables the default vehicle never produces -- wide, of mixed sign, all negative,
+    with inf / NaN entries -- installed through f110_set_tables: collisions, states and scans of a wall-hugging rollout
+    stay identical to oracle envs holding the same table (check_ttc_jit, laser_models.py:189-217)."""
+    from red_gym_amd import F110VecEnv, _lib
+    from red_gym_amd.engine import _np_ptr
+    B, T, nb = 8, 60, 1080
+    sc = oracle.Scanner(nb, 2 * np.pi)
+    sc.set_map(os.path.join(assets, 'example_map.yaml'), '.png')
+    rng = np.random.default_rng(5)
+    side = np.array(sc.side_distances)
+    if kind == 'wide':
+        side = rng.uniform(0.2, 1.5, nb)
+    elif kind == 'mixed_sign':
+        side = rng.uniform(-0.5, 0.8, nb)
+    elif kind == 'negative':
+        side = -rng.uniform(0.01, 0.6, nb)
+    else:
+        side = rng.uniform(0.1, 0.9, nb)
+        side[::7] = np.inf; side[3::11] = -np.inf; side[5::13] = np.nan
+    sc.side_distances[:] = side
+    env = F110VecEnv(B, map=os.path.join(assets, 'example_map'), num_agents=1, autoreset=False, keep_f64_scans=True)
+    e = env.eng
+    e.side_distances = np.ascontiguousarray(side)
+    _lib.check(e.lib.f110_set_tables(e._h, _np_ptr(e.sines), _np_ptr(e.cosines), _np_ptr(e.scan_angles), _np_ptr(e.beam_cosines),
+                                     _np_ptr(e.side_distances)))
+    m = sc.map
+    near = np.argwhere((m['dt'] > 0.25) & (m['dt'] < 0.9))    # close to walls: many scan values within reach of the side table
+    pick = near[rng.choice(len(near), size=B, replace=False)]
+    poses = np.zeros((B, 1, 3))
+    poses[:, 0, 0] = m['orig_x'] + (pick[:, 1] + 0.5) * m['resolution']
+    poses[:, 0, 1] = m['orig_y'] + (pick[:, 0] + 0.5) * m['resolution']
+    poses[:, 0, 2] = rng.uniform(0, 6.28, B)
+    noise = oracle.noise_table(12345, T + 2, num_beams=nb)
+    ors = [oracle.Env(sc, 1, noise=noise) for _ in range(B)]
+    env.reset(poses)
+    for b in range(B):
+        ors[b].reset(poses[b])
+    hits = 0
+    for k in range(T):
+        act = np.stack([rng.uniform(-0.4, 0.4, (B, 1)), rng.uniform(0.5, 7, (B, 1))], axis=2)
+        obs, _, done, info = env.step(act)
+        oo = [ors[b].step(act[b]) for b in range(B)]
+        st = _np(env.state)
+        for b in range(B):
+            assert np.array_equal(_np(obs['collisions'])[b].astype(np.float64), oo[b]['collisions']), (kind, k, b)
+            assert np.allclose(st[b], oo[b]['state'], rtol=0, atol=1e-9), (kind, k, b)
+            assert np.allclose(_np(obs['scans_f64'])[b], oo[b]['scans'], rtol=0, atol=1e-9), (kind, k, b)
+            hits += int(oo[b]['collisions'][0])
+    if kind in ('wide', 'mixed_sign'):
+        assert hits > 0   # the rare path did fire
+    env.close()
