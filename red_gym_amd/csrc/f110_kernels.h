@@ -1020,6 +1020,10 @@ __global__ __launch_bounds__(256) void dynamics_kernel(DynArgs a)
         steer = a.actions[(size_t)car * 2];
         speed = a.actions[(size_t)car * 2 + 1];
     }
+    // (the noise window's bounds and the car's row travel with the loads above: read after the stores below they were one more
+    // memory round trip at the end of a kernel that is nothing but latency)
+    int nrow = 0, nlo = 0, nhi = 0x7fffffff;
+    if (a.noise && a.noise_step) { nrow = pend ? 0 : a.noise_step[car]; nlo = a.noise->lo; nhi = a.noise->hi; }
     const Params P = a.params[(size_t)params_slot_of(a.env_params, env, a.param_slots, a.dev_err) * (a.agents + 1) + 1 + car % a.agents];
     update_pose(st, sb, sc, steer, speed, P, a.time_step, a.integrator);
 #pragma unroll
@@ -1028,12 +1032,9 @@ __global__ __launch_bounds__(256) void dynamics_kernel(DynArgs a)
     a.steer_buf[(size_t)car * 2 + 1] = sb[1];
     a.steer_cnt[car] = sc;
     if (a.in_collision) a.in_collision[car] = 0;
-    if (a.noise && a.noise_step) {
-        // the host keeps the noise table ahead of every car (Engine._ensure_noise); a row outside it is reported, never silent
-        const int row = pend ? 0 : a.noise_step[car];
-        if (__builtin_expect(row < a.noise->lo || row >= a.noise->hi, 0))
-            if (a.dev_err) atomicOr(a.dev_err, DEVERR_NOISE_WINDOW);
-    }
+    // the host keeps the noise table ahead of every car (Engine._ensure_noise); a row outside it is reported, never silent
+    if (__builtin_expect(nrow < nlo || nrow >= nhi, 0))
+        if (a.dev_err) atomicOr(a.dev_err, DEVERR_NOISE_WINDOW);
     if (a.pose_snap) {
         a.pose_snap[(size_t)car * 3] = st[0];
         a.pose_snap[(size_t)car * 3 + 1] = st[1];
