@@ -1420,7 +1420,9 @@ static int launch_scan(f110_handle *h, const ScanArgs &a_in, const Sink &st, hip
         std::vector<St> spec;
         const char *why = nullptr;
         if (!stages_env || !parse_stage_spec(stages_env, spec, &why)) { // (a malformed F110_STAGES: the built-in choice)
-            const int tail = std::min(2048, a.n_cars / 2);
+            // (envs of several agents: 4 096 -- 16 384 x 2: scan 0.396 -> 0.388 ms, 32 768 x 2: 0.697 -> 0.672; 8 192 x 4: flat;
+            // one agent: 4 096 is 1 % worse than 2 048 at 65 536 cars and 2.5 % worse at 32 768; profiles/r04_scan_stores.txt N)
+            const int tail = std::min(a.agents >= 2 ? 4096 : 2048, a.n_cars / 2);
             spec = {{-1, 0}, {tail, 2}};
         }
         int fixed = 0;
