@@ -167,8 +167,16 @@ __device__ inline double dist_lookup(const MapView &m, const double *lds_lut, do
 {
     int ci, ri;
     cell_index<IDENT, POW2>(m, x, y, ci, ri);
+#if defined(F110_X_NOCLAMP) // timing experiment (round 5): two VALU instructions fewer per iteration (valid while rays stay on the map)
+    const int cc = ci, rr = ri;
+#else
     const int cc = med3_i32(ci, -1, m.W);      // column -1..W (both ends are border cells)
     const int rr = med3_i32(ri, -1, m.H);      // row -1..H
+#endif
+#if defined(F110_X_EXTRA_VALU) // timing experiment: that many VALU instructions more per iteration (results unchanged)
+#pragma unroll
+    for (int k_ = 0; k_ < F110_X_EXTRA_VALU; k_++) asm volatile("v_mov_b32 %0, %0" : "+v"(ci));
+#endif
     // Byte offset of cell (rr, cc): strip (cc >> 3) + 1 (arithmetic shift: column -1 is the last column of
     // strip 0), 16 bytes per row inside a strip.  The +1 strip and the +1 border row ride in the constant
     // of the shift-add (`row_bias` = strip_bytes + 16, a multiple of 16), so no add is spent on the padding
