@@ -43,30 +43,59 @@ __global__ void probe(const uint16_t *lo, const uint16_t *hi, unsigned stride, u
     }
 }
 
-// rate: a dependent chain of gathers as in the march -- 64 lanes on `lines` 8x8 blocks around a moving centre
-template <int MODE> // 0: raw offen with the offset arithmetic of the shipped kernel; 1: swizzled idxen offen
-__global__ void rate(const uint16_t *tab, unsigned bytes, unsigned stride, unsigned rows, unsigned w3, int iters, int spread, unsigned *out)
+// rate: a dependent chain of gathers as in the march; identical footprints in every mode (the swizzled 8x8-block layout)
+//   MODE 0: raw descriptor, `offen`, the swizzled byte offset formed by VALU instructions
+//   MODE 1: linear structured descriptor (stride = one band of 8 rows), `idxen offen`: index = row >> 3, offset = the rest (VALU)
+//   MODE 2: swizzled structured descriptor, `idxen offen`: index = row, offset = 2 * column
+//   PAT 0: the wave's 64 lanes inside one 8x8 block (1 line); 1: each 16-lane group in its own block (4 lines);
+//       2: each quad of lanes in its own block (16 lines); 3: every lane its own block (64 lines)
+template <int MODE, int PAT>
+__global__ void rate(const uint16_t *tab, unsigned bytes, unsigned stride, unsigned rows, int iters, unsigned *out)
 {
     const int lane = threadIdx.x & 63;
-    unsigned r = 64 + ((blockIdx.x * 7 + (threadIdx.x >> 6) * 13) & 255) + (lane >> 3) * (spread >> 3);
-    unsigned c = 64 + ((blockIdx.x * 11) & 511) + (lane & 7) * (spread & 7 ? spread : 8);
+    const unsigned wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    unsigned r0 = (wave * 40u) & 1016u, c0 = (wave * 72u) & 1016u; // block-aligned
+    unsigned dr, dc;
+    if (PAT == 0) { dr = lane >> 3; dc = lane & 7; }
+    else if (PAT == 1) { dr = (lane >> 2) & 3; dc = (lane & 3) + 8 * (lane >> 4); }
+    else if (PAT == 2) { dr = (lane & 1) + 8 * ((lane >> 4) & 3); dc = ((lane >> 1) & 1) + 8 * ((lane >> 2) & 3); }
+    else { dr = 8 * (lane >> 3); dc = 8 * (lane & 7); }
     unsigned acc = 0;
-    if (MODE == 0) {
-        auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(tab), 0, (int)bytes, 0x00020000);
-        const unsigned strip = rows * 16u;
-        for (int i = 0; i < iters; i++) {
-            const unsigned o = (c >> 3) * strip + r * 16u + (c & 7u) * 2u;
-            const unsigned v = (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rs, (int)o, 0, 0);
-            acc += v; r = ((r + 3u + v) & 1023u); c = ((c + 5u + v) & 1023u);
+    const u32x4 rl = make_rsrc(tab, stride * 8u, (rows + 7u) >> 3, 0u, 0x00020000u);
+    const u32x4 rs = make_rsrc(tab, stride, rows, 0x80000000u, 0x00020000u);
+    auto rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(tab), 0, (int)bytes, 0x00020000);
+    for (int i = 0; i < iters; i++) {
+        const unsigned r = (r0 + dr) & 1023u, c = (c0 + dc) & 1023u;
+        unsigned v;
+        if (MODE == 0) {
+            const unsigned o = ((r >> 3) * stride + (c >> 1) * 4u) * 8u + (r & 7u) * 4u + (c & 1u) * 2u;
+            v = (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rr, (int)o, 0, 0);
+        } else if (MODE == 1) {
+            v = load_u16_struct(rl, r >> 3, (c >> 1) * 32u + (r & 7u) * 4u + (c & 1u) * 2u);
+        } else {
+            v = load_u16_struct(rs, r, c * 2u);
         }
-    } else {
-        const u32x4 rs = make_rsrc(tab, stride, rows, 0x80000000u, w3);
-        for (int i = 0; i < iters; i++) {
-            const unsigned v = load_u16_struct(rs, r, c * 2u);
-            acc += v; r = ((r + 3u + v) & 1023u); c = ((c + 5u + v) & 1023u);
-        }
+        acc += v; r0 = (r0 + 24u + v) & 1016u; c0 = (c0 + 40u + v) & 1016u; // table is all zeros: v only carries the dependence
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+
+template <int MODE, int PAT>
+static void time_rate(const uint16_t *tab, unsigned bytes, unsigned stride, unsigned rows, int cus, unsigned *dout, hipEvent_t e0, hipEvent_t e1)
+{
+    const int iters = 4000;
+    float best = 1e9f;
+    for (int rep = 0; rep < 3; rep++) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((rate<MODE, PAT>), dim3(cus * 8), dim3(256), 0, 0, tab, bytes, stride, rows, iters, dout);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) best = ms;
+    }
+    static const char *mn[] = {"raw offen + VALU offset", "linear idxen offen", "swizzled idxen offen"};
+    static const char *pn[] = {"1 line", "4 lines (one per 16-lane group)", "16 lines (one per quad)", "64 lines"};
+    printf("rate %-26s %-34s %.3f ms  %.2f ns per wave-gather per CU\n", mn[MODE], pn[PAT], best, best * 1e6 / iters / 32.0); fflush(stdout);
 }
 
 int main(int argc, char **argv)
@@ -122,24 +151,12 @@ int main(int argc, char **argv)
     }
     hipDeviceProp_t p;
     hipGetDeviceProperties(&p, 0);
-    const int cus = p.multiProcessorCount, iters = 4000;
+    const int cus = p.multiProcessorCount;
     hipMemset(lo, 0, cells * 2);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int spread = 8; spread <= 24; spread += 8)
-        for (int mode = 0; mode < 2; mode++) {
-            float best = 1e9f;
-            for (int rep = 0; rep < 3; rep++) {
-                hipEventRecord(e0);
-                if (mode == 0) hipLaunchKernelGGL(rate<0>, dim3(cus * 8), dim3(256), 0, 0, lo, (unsigned)(cells * 2), stride, H, 0u, iters, spread, dout);
-                else hipLaunchKernelGGL(rate<1>, dim3(cus * 8), dim3(256), 0, 0, lo, (unsigned)(cells * 2), stride, H, 0x00020000u, iters, spread, dout);
-                hipEventRecord(e1);
-                hipEventSynchronize(e1);
-                float ms; hipEventElapsedTime(&ms, e0, e1);
-                if (ms < best) best = ms;
-            }
-            printf("rate spread %2d %s: %.3f ms, %.1f cycles per wave-gather per CU slot @2.4 GHz\n", spread, mode ? "swizzled idxen offen" : "raw offen + VALU offset",
-                   best, best * 1e-3 * 2.4e9 / iters / 8.0); fflush(stdout);
-        }
+    const unsigned bytes = (unsigned)(cells * 2);
+#define ROW(P) time_rate<0, P>(lo, bytes, stride, H, cus, dout, e0, e1); time_rate<1, P>(lo, bytes, stride, H, cus, dout, e0, e1); time_rate<2, P>(lo, bytes, stride, H, cus, dout, e0, e1);
+    ROW(0) ROW(1) ROW(2) ROW(3)
     return 0;
 }

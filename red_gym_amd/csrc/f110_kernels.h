@@ -56,57 +56,99 @@ constexpr int SCAN_WAVES = F110_SCAN_WAVES;   // cars per workgroup (one wavefro
 constexpr int SCAN_THREADS = SCAN_WAVES * WAVE;
 constexpr int REFILL_MIN_IDLE = F110_REFILL_MIN_IDLE; // refill the wave's beam slots once this many lanes idle
 
-// Cell table.  Each map cell stores, as a u16, the BYTE OFFSET of its distance inside the LDS
-// copy of the LUT: 8*k, k = RANK of the cell's exact squared distance d2 (in cells, to the
-// nearest obstacle) among the distinct d2 values of the map, for k <= 1021 (squared
-// distances are sums of two squares, so that reaches d2 ~ 3 900 = 62 cells); OFF_FAR for
-// larger ranks and for cells of a user table that are not resolution*sqrt(int) -- those
-// re-read a second table (u16 rank, 65535 = "use the fp64 table") in a rarely taken branch.
-// Rank 0 is always d2 = 0, so LDS offset 0 is the distance 0.0.
-// The table has a one-cell BORDER on every side holding OFF_BORDER, whose LDS slot holds
-// dt[-1,-1]: the reference's out-of-bounds read (laser_models.py:80-81,:103) becomes an
-// ordinary lookup of a clamped index -- no bounds compare, no select, no index clamp or
-// scaling in the march loop (the loaded value addresses the ds_read directly).
-// Layout: 8-column strips, map cell (r, c), r in -1..H, c in -1..W, at [(c >> 3) + 1][r + 1][c & 7] (arithmetic
-// shift: the left border column is the last column of strip 0), so one 128-B cache line holds an 8x8-cell block.  The 64 rays of a wave sample neighbouring
-// points, so a gather touches fewer lines than with a row-major table (which measured
-// ~40 L1 accesses per 64-lane gather and made the kernel L1-tag-rate bound), and the byte
-// offset is two shift-adds and one multiply-add: (c >> 3) * (strip_bytes - 16) + (c << 1) + (r << 4) + strip_bytes + 16.
+// Cell table.  Each map cell stores, as a u16, the BYTE OFFSET of its distance inside the LDS copy of the LUT:
+// 8 * (k + 1), k = RANK of the cell's exact squared distance d2 (in cells, to the nearest obstacle) among the distinct d2
+// values of the map, for k < LDS_RANKS = 1022 (squared distances are sums of two squares, so that reaches d2 ~ 3 900 =
+// 62 cells); OFF_FAR for larger ranks and for cells of a user table that are not resolution*sqrt(int) -- those re-read a
+// second table (u16 rank, 65535 = "use the fp64 table") in a rarely taken branch.
+// Code 0 is what a look-up OUTSIDE the map reads, and LDS slot 0 holds dt[-1,-1], the value the reference reads there
+// (laser_models.py:80-81,:103).
+//
+// Layout and addressing (round 5).  The table is read through a SWIZZLED structured buffer descriptor (GFX9: descriptor bit
+// 63; the swizzle element is a dword, INDEX_STRIDE 8; profiles/r05_swizzle_probe.txt shows gfx950 still implements it):
+// `buffer_load_ushort v, v[index:offset], s[rsrc], 0 idxen offen` with index = the cell's ROW and offset = 2 * its COLUMN
+// reads byte
+//     ((row >> 3) * stride + (col >> 1) * 4) * 8 + (row & 7) * 4 + (col & 1) * 2,        stride = bytes of one table row,
+// so one 128-B cache line holds an 8 x 8-cell block -- the 64 rays of a wave sample neighbouring points, and a gather over
+// such blocks touches fewer lines than one over rows (a row-major table measured ~40 L1 accesses per 64-lane gather) --
+// without ONE address instruction in the march loop, and the descriptor's range check (index >= num_records = H, which a
+// negative row is too once it is read as unsigned) answers 0 for a row outside the map: no clamp of the row either.
+// The hardware does NOT check the offset against the stride (same probe), so the column is clamped to [0, W] with one
+// v_min_u32 (a negative column read as unsigned is large: it lands on column W as well) and column W of every row holds
+// code 0.  Rounds 1-4 clamped both coordinates and formed the offset of an equivalent strip layout with six VALU
+// instructions per look-up; this is two (the clamp and the shift that scales the column to bytes).
+// stride is a 14-bit field: tables up to 8 184 columns; wider maps are refused at installation.
 #ifndef F110_LUT_LDS
 #define F110_LUT_LDS 1024
 #endif
 constexpr int LUT_LDS = F110_LUT_LDS;                   // LDS LUT slots
-constexpr unsigned SLOT_FAR = LUT_LDS - 2, SLOT_BORDER = LUT_LDS - 1;
-constexpr unsigned OFF_FAR = 8 * SLOT_FAR, OFF_BORDER = 8 * SLOT_BORDER;
+constexpr unsigned SLOT_OOB = 0, SLOT_FAR = LUT_LDS - 1; // slot 0: dt[-1,-1]; slots 1 .. LUT_LDS-2: ranks 0 .. LDS_RANKS-1; last: far marker
+constexpr unsigned LDS_RANKS = LUT_LDS - 2;
+constexpr unsigned OFF_FAR = 8 * SLOT_FAR;
 constexpr unsigned CODE_ESC = 65535;                    // second table: read the fp64 table instead
+constexpr int MAP_MAX_W = 8184;                         // (W + 1 rounded up to 8 columns) * 2 B <= the 14-bit stride field
+// the far marker's LDS slot holds -0.0: as a distance it is an exact no-op (total += -0.0, x += -0.0 * c) that ends the ray's
+// march (-0.0 > eps is false); the wave looks at the sign of its parked lanes' last distance once per refill, not once per look-up
+__host__ __device__ inline unsigned cell_code(unsigned rank) { return rank < LDS_RANKS ? 8u * (rank + 1u) : OFF_FAR; }
+__host__ __device__ inline unsigned map_row_bytes(int W) { return (unsigned)(((W + 1 + 7) >> 3) << 3) * 2u; }
+__host__ __device__ inline size_t map_cells_bytes(int H, int W) { return (size_t)((H + 7) >> 3) * 8u * map_row_bytes(W); }
+// byte offset of cell (r, c), 0 <= r < H, 0 <= c <= W, in the swizzled table (what the address unit forms from index r, offset 2c)
+__host__ __device__ inline size_t cell_byte(unsigned r, unsigned c, unsigned row_bytes)
+{
+    return ((size_t)(r >> 3) * row_bytes + (size_t)(c >> 1) * 4u) * 8u + (r & 7u) * 4u + (c & 1u) * 2u;
+}
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct MapDev {
-    const uint16_t *cells;  // padded strips [(W >> 3) + 2][Hp][8] of LDS byte offsets
+    const uint16_t *cells;  // swizzled table of LDS byte offsets (see above): H rows (rounded up to 8) of row_bytes
     const uint16_t *cells_far; // same layout: rank (<= 65534) of the cells marked OFF_FAR, 65535 = fp64 table
     unsigned cells_bytes;
-    unsigned strip_bytes;   // Hp * 16, Hp = H + 2 rounded up to a multiple of 8
+    unsigned row_bytes;     // stride of the descriptor: (W + 1 rounded up to 8) * 2
     const double *lut;      // [lut_len <= 65535] resolution*sqrt(d2_k), indexed by rank k
-    const double *lut_lds;  // [LUT_LDS] image staged in LDS: lut[0..SLOT_FAR-1], unused, dt[-1,-1]
+    const double *lut_lds;  // [LUT_LDS] image staged in LDS: dt[-1,-1], lut[0..LDS_RANKS-1], -0.0
     const double *dt;       // [H*W] exact fp64 distance table (escape path, rarely touched)
     int H, W;
     double res, rinv, ox, oy, oc, os, wres, hres, oob; // oob = dt[H-1][W-1]
     unsigned lut_len;       // entries of lut
 };
 
-// device-side view of MapDev with the cell table behind a buffer resource descriptor
+// swizzled structured descriptor of a cell table: word 1 = base[47:32] | stride << 16 | swizzle enable (bit 31), word 2 =
+// num_records (rows), word 3 = data format 32 (as the raw descriptors of this library) with INDEX_STRIDE 0 (= 8 records).
+// Bits 19-20 of word 3 are NOT an element size on GFX9 (USER_VM_ENABLE / MODE: setting them faults).
+__device__ inline u32x4 make_cells_rsrc(const uint16_t *base, unsigned row_bytes, int rows)
+{
+    const unsigned long long a = (unsigned long long)base;
+    u32x4 r;
+    r.x = (unsigned)a;
+    r.y = ((unsigned)(a >> 32) & 0xffffu) | (row_bytes << 16) | 0x80000000u;
+    r.z = (unsigned)rows;
+    r.w = 0x00020000u;
+    return r;
+}
+
+// one look-up of the cell table: the load and its wait in one statement (the compiler does not count an asm load)
+__device__ inline unsigned load_cell(const u32x4 &rsrc, int row, unsigned col2)
+{
+    unsigned v;
+    const unsigned long long io = (unsigned long long)(unsigned)row | ((unsigned long long)col2 << 32);
+    asm volatile("buffer_load_ushort %0, %1, %2, 0 idxen offen\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(io), "s"(rsrc));
+    return v;
+}
+
+// device-side view of MapDev with the cell table behind its descriptor
 struct MapView {
-    __amdgpu_buffer_rsrc_t cells_rsrc;
-    unsigned strip_bytes, row_bias, strip_m16; // row_bias = strip_bytes + 16, strip_m16 = strip_bytes - 16
+    u32x4 cells_rsrc;
     const MapDev *desc;  // rare paths (far cells, escape cells) re-read their table pointers from the descriptor:
-                         // three 64-bit pointers less to keep in scalar registers across the march loop
+                         // pointers that need not be kept in scalar registers across the march loop
     int H, W;
     double res, rinv, ox, oy, oc, os, wres, hres;
     double nox, noy; // -ox * rinv, -oy * rinv (exact when rinv is a power of two)
-    F110_BOUNDS_ONLY(uint32_t *err = nullptr; unsigned cells_bytes = 0;)
+    F110_BOUNDS_ONLY(uint32_t *err = nullptr;)
     __device__ void init(const MapDev &m)
     {
-        F110_BOUNDS_ONLY(cells_bytes = m.cells_bytes;)
-        strip_bytes = m.strip_bytes; row_bias = m.strip_bytes + 16u; strip_m16 = m.strip_bytes - 16u; desc = &m; H = m.H; W = m.W; res = m.res; rinv = m.rinv;
+        cells_rsrc = make_cells_rsrc(m.cells, m.row_bytes, m.H);
+        desc = &m; H = m.H; W = m.W; res = m.res; rinv = m.rinv;
         ox = m.ox; oy = m.oy; oc = m.oc; os = m.os; wres = m.wres; hres = m.hres;
         nox = -m.ox * m.rinv; noy = -m.oy * m.rinv;
     }
@@ -123,10 +165,9 @@ struct ScanDev {
 // laser_models.py:56-104: (x, y) -> distance-table value, branch-free.  IDENT: origin
 // yaw == 0 (c=1, s=0: the rotation is the identity in exact arithmetic).  POW2:
 // resolution is a power of two, so q = x_rot * (1/res) IS the reference's quotient and
-// "x_rot < 0 or x_rot >= width*res" (:79) is exactly "floor(q) outside [0, W)", which the
-// clamp to [-1, W] maps onto the table's border.
+// "x_rot < 0 or x_rot >= width*res" (:79) is exactly "floor(q) outside [0, W)".
 // laser_models.py:71-84 (xy_2_rc): the cell (column ci, row ri) of a point, un-clamped (a saturating conversion: any value
-// outside [0, W) x [0, H) means "out of bounds", which the callers map onto the reference's dt[-1, -1] read).
+// outside [0, W) x [0, H) means "out of bounds", which dist_lookup maps onto the reference's dt[-1, -1] read).
 template <bool IDENT, bool POW2>
 __device__ inline void cell_index(const MapView &m, double x, double y, int &ci, int &ri)
 {
@@ -145,7 +186,7 @@ __device__ inline void cell_index(const MapView &m, double x, double y, int &ci,
         qy = yr * m.rinv;
     }
     const double fx = floor(qx), fy = floor(qy);
-    ci = (int)fx; ri = (int)fy; // saturating conversion; the callers' clamp / bounds test finishes the job
+    ci = (int)fx; ri = (int)fy; // saturating conversion; the column clamp / the descriptor's row check finish the job
     if (!POW2) {
         // int(x_rot/resolution) and the bounds test need the IEEE quotient: x_rot*(1/res) is
         // within ~2e-12 of it, so only quotients within 1e-9 of an integer (where truncation
@@ -162,68 +203,54 @@ __device__ inline void cell_index(const MapView &m, double x, double y, int &ci,
     }
 }
 
+// One table look-up (laser_models.py:56-104 distance_transform): the value of the cell under (x, y), or -0.0 when the cell
+// carries the far marker (dist_lookup_far finishes those).  The caller runs it under the EXEC mask of the rays that are
+// still marching: a finished ray issues nothing.
 template <bool IDENT, bool POW2>
-__device__ inline double dist_lookup(const MapView &m, const double *lds_lut, double x, double y, bool live)
+__device__ inline double dist_lookup(const MapView &m, const double *lds_lut, double x, double y)
 {
     int ci, ri;
     cell_index<IDENT, POW2>(m, x, y, ci, ri);
-#if defined(F110_X_NOCLAMP) // timing experiment (round 5): two VALU instructions fewer per iteration (valid while rays stay on the map)
-    const int cc = ci, rr = ri;
-#else
-    const int cc = med3_i32(ci, -1, m.W);      // column -1..W (both ends are border cells)
-    const int rr = med3_i32(ri, -1, m.H);      // row -1..H
-#endif
-#if defined(F110_X_EXTRA_VALU) // timing experiment: that many VALU instructions more per iteration (results unchanged)
-#pragma unroll
-    for (int k_ = 0; k_ < F110_X_EXTRA_VALU; k_++) asm volatile("v_mov_b32 %0, %0" : "+v"(ci));
-#endif
-    // Byte offset of cell (rr, cc): strip (cc >> 3) + 1 (arithmetic shift: column -1 is the last column of
-    // strip 0), 16 bytes per row inside a strip.  The +1 strip and the +1 border row ride in the constant
-    // of the shift-add (`row_bias` = strip_bytes + 16, a multiple of 16), so no add is spent on the padding
-    // and the offset never goes negative; asm so that the constant is not re-associated into a trailing add.
-    // (c >> 3) * S + (c & 7) * 2 == (c >> 3) * (S - 16) + c * 2: no masking of the column bits needed
-    unsigned row16;
-    asm("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(row16) : "v"(rr), "s"(m.row_bias));
-    unsigned rc;
-    asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(rc) : "v"(cc), "v"(row16));
-    unsigned off = (unsigned)(__mul24(cc >> 3, (int)m.strip_m16) + (int)rc);
-    // a finished ray presents an out-of-range offset: the hardware range check answers 0
-    // (= LDS offset 0 = distance 0.0, which parks the ray: total += 0, x += 0*c) without
-    // occupying the L1 tag pipeline
-    off = live ? off : 0xffffffffu;
-    // buffer load: 32-bit per-lane offset against a scalar descriptor
-    unsigned code = (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(m.cells_rsrc, (int)off, 0, 0);
+    // column: [0, W) as it is, everything else (negative columns are large unsigned values) -> column W, which holds code 0;
+    // row: the descriptor's range check (index >= H) answers code 0 by itself
+    const unsigned col2 = min((unsigned)ci, (unsigned)m.W) << 1;
 #if defined(F110_BOUNDS)
-    F110_BCHK(!live || off + 2u <= m.cells_bytes, BT_LUT_CODE, m.err);
-    F110_BCHK(code <= OFF_BORDER && (code & 7u) == 0u, BT_LUT_CODE, m.err);
-    code = code <= OFF_BORDER ? (code & ~7u) : 0u;
+    F110_BCHK((size_t)col2 + 2u <= m.desc->row_bytes, BT_LUT_CODE, m.err);
+    const bool row_in = (unsigned)ri < (unsigned)m.H;
+    F110_BCHK(!row_in || cell_byte((unsigned)ri, col2 >> 1, m.desc->row_bytes) + 2u <= m.desc->cells_bytes, BT_LUT_CODE, m.err);
 #endif
-    // common case: the loaded value IS the LDS byte offset of the distance: one ds_read_b64
+    unsigned code = load_cell(m.cells_rsrc, ri, col2);
+#if defined(F110_BOUNDS)
+    F110_BCHK(code <= OFF_FAR && (code & 7u) == 0u, BT_LUT_CODE, m.err);
+    F110_BCHK(row_in || code == 0u, BT_LUT_CODE, m.err); // (the range check's answer)
+    code = code <= OFF_FAR ? (code & ~7u) : 0u;
+#endif
+    // the loaded value IS the LDS byte offset of the distance: one ds_read_b64
     double d = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(lds_lut) + code);
-    // pin the LDS read: otherwise the compiler folds it and the rare global reads below
-    // into one flat_load through a selected generic pointer
-    asm volatile("" : "+v"(d));
-    const bool far = code == OFF_FAR;
-    if (__builtin_expect(vote(far) != 0ull, 0)) {
-        if (far) {
-            const MapDev *dp = m.desc;
-            asm volatile("" : "+s"(dp)); // opaque: the loads below stay here instead of being hoisted to the kernel entry
-#if defined(F110_BOUNDS)
-            F110_BCHK(off + 2u <= dp->cells_bytes, BT_CELLS_FAR, m.err);
-            if (off + 2u > dp->cells_bytes) off = 0u;
-#endif
-            unsigned rank = *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(dp->cells_far) + (size_t)off);
-#if defined(F110_BOUNDS)
-            F110_BCHK(rank == CODE_ESC || rank < dp->lut_len, BT_LUT_RANK, m.err);
-            if (rank != CODE_ESC && rank >= dp->lut_len) rank = 0u;
-            F110_BCHK(rank != CODE_ESC || ((unsigned)rr < (unsigned)m.H && (unsigned)cc < (unsigned)m.W), BT_DT, m.err); // (a border cell never carries the far marker)
-            if (rank == CODE_ESC && !((unsigned)rr < (unsigned)m.H && (unsigned)cc < (unsigned)m.W)) rank = 0u;
-#endif
-            d = (rank != CODE_ESC) ? dp->lut[rank] : dp->dt[(size_t)(unsigned)rr * (unsigned)m.W + (unsigned)cc];
-        }
-    }
+    asm volatile("" : "+v"(d)); // pin the LDS read (keeps it a ds_read, not a flat load through a selected pointer)
     return d;
 }
+
+// the rare path behind the far marker: the cell's full rank from the second table, then the global LUT or the fp64 table
+template <bool IDENT, bool POW2>
+__device__ inline double dist_lookup_far(const MapView &m, double x, double y)
+{
+    int ci, ri;
+    cell_index<IDENT, POW2>(m, x, y, ci, ri);
+    const MapDev *dp = m.desc;
+    asm volatile("" : "+s"(dp)); // opaque: the loads below stay here instead of being hoisted to the kernel entry
+    // (a cell with the far marker is inside the map: 0 <= ri < H, 0 <= ci < W)
+    bool ok = (unsigned)ri < (unsigned)m.H && (unsigned)ci < (unsigned)m.W;
+    F110_BCHK(ok, BT_CELLS_FAR, m.err);
+    if (!ok) return dp->oob;
+    unsigned rank = *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(dp->cells_far) + cell_byte((unsigned)ri, (unsigned)ci, dp->row_bytes));
+#if defined(F110_BOUNDS)
+    F110_BCHK(rank == CODE_ESC || rank < dp->lut_len, BT_LUT_RANK, m.err);
+    if (rank != CODE_ESC && rank >= dp->lut_len) rank = 0u;
+#endif
+    return (rank != CODE_ESC) ? dp->lut[rank] : dp->dt[(size_t)(unsigned)ri * (unsigned)m.W + (unsigned)ci];
+}
+__device__ inline bool is_far_marker(double d) { return __double2hiint(d) == (int)0x80000000; } // -0.0 (no table value is negative)
 
 // np.fmod(t, td) (laser_models.py:170) without the generic library loop: for |t/td| < 2^31
 // the result t - trunc(t/td)*td is exact (fmod results are representable and q*td is an
@@ -378,18 +405,18 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
     if ((unsigned)map_slot >= 64u) map_slot = 0;
 #endif
     const MapDev &md = a.maps[map_slot];
-    {   // LDS image of the LUT prepared by the host (slot SLOT_BORDER = dt[-1,-1]): 16-B copies
+    {   // LDS image of the LUT prepared by the host (slot 0 = dt[-1,-1], last slot = the far marker): 16-B copies
         const double2 *src = reinterpret_cast<const double2 *>(md.lut_lds);
         double2 *dst = reinterpret_cast<double2 *>(s_lut);
         for (int i = threadIdx.x; i < LUT_LDS / 2; i += SCAN_THREADS) dst[i] = src[i];
     }
-    for (int i = threadIdx.x; i < ((nb + 63) >> 6); i += SCAN_THREADS) s_chunk0[i] = a.chunk_beam0[i];
+    static_assert(MAX_CHUNKS <= SCAN_THREADS, "one pass stages the chunk table");
+    if ((int)threadIdx.x < ((nb + 63) >> 6)) s_chunk0[threadIdx.x] = a.chunk_beam0[threadIdx.x];
 #if defined(F110_TIMELINE)
     { unsigned long long t = wall_clock64(); asm volatile("" : "+v"(t)); if (lane == 0) s_tl[wave][0] = t; }
 #endif
     __syncthreads();
     MapView mv;
-    mv.cells_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(md.cells), 0, (int)md.cells_bytes, 0x00020000);
     mv.init(md);
     F110_BOUNDS_ONLY(mv.err = rare->dev_err;)
     if (car >= a.n_cars) return;
@@ -467,7 +494,8 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
 
     // ---- ray march (laser_models.py:107-186) -------------------------------------
     // The first table read of every beam is at the car itself (:129): done once.
-    const double d0 = dist_lookup<IDENT, POW2>(mv, s_lut, px, py, true);
+    double d0 = dist_lookup<IDENT, POW2>(mv, s_lut, px, py);
+    if (__builtin_expect(is_far_marker(d0), 0)) d0 = dist_lookup_far<IDENT, POW2>(mv, px, py); // (wave-uniform: every lane reads the car's own cell)
 #if defined(F110_TIMELINE)
     { unsigned long long t = wall_clock64(); asm volatile("" : "+v"(t)); if (lane == 0) s_tl[wave][1] = t; }
 #endif
@@ -500,8 +528,23 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
         bool active = false;
         int beam = -1;          // beam whose result `total` holds (-1: none)
         double x = px, y = py, c = 0, s = 0, total = 0;
+        double d = 0;           // the lane's last table value (kept across the phases: a parked -0.0 is a cell of the second table)
         double nz = 0;          // noise of the lane's beam (fetched when the beam is taken)
         for (;;) {
+            // ---- cells of the second table (rare): a lane that read the far marker stopped with an exact no-op; finish its
+            // look-up here, once per phase instead of one compare per look-up
+            {
+                const bool farp = !active && is_far_marker(d);
+                if (__builtin_expect(vote(farp) != 0ull, 0)) {
+                    if (farp) {
+                        d = dist_lookup_far<IDENT, POW2>(mv, x, y);
+                        total += d;
+                        x += d * c;
+                        y += d * s;
+                        active = (d > eps) && (total <= max_range);
+                    }
+                }
+            }
             // ---- refill phase: idle lanes finish their beam and take the next one ----
             const unsigned long long idle = vote(!active);
             const int nidle = __popcll(idle);
@@ -545,8 +588,8 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
             next += nidle;
             int nact = __popcll(vote(active));
             if (nact == 0) break;
-            // ---- march phase: every lane steps (idle lanes are parked by d = 0) until
-            // enough lanes are idle again or, once no beams are left, the wave has drained ----
+            // ---- march phase: the rays that are still marching step, under their own EXEC mask (a finished ray issues no
+            // look-up and keeps its total), until enough lanes are idle again or, once no beams are left, the wave has drained ----
             const int go = next < nbl ? WAVE - REFILL_MIN_IDLE : 0; // keep marching while nact > go
 #if defined(F110_DRAIN_PRIO)
             if (go == 0) __builtin_amdgcn_s_setprio(F110_DRAIN_PRIO); // experiment: a draining wave ends on its longest ray's dependent chain
@@ -559,13 +602,14 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
                 tl_wit++;
 #endif
                 nlook += (unsigned)nact;
-                const double d = dist_lookup<IDENT, POW2>(mv, s_lut, x, y, active);
-                total += d;
-                x += d * c;
-                y += d * s;
-                const bool c1 = d > eps, c2 = total <= max_range;
-                active = c1 && c2;
-                nact = __popcll(vote(c1) & vote(c2)); // two direct compare masks: no bool round trip
+                if (active) {
+                    d = dist_lookup<IDENT, POW2>(mv, s_lut, x, y);
+                    total += d;
+                    x += d * c;
+                    y += d * s;
+                    active = (d > eps) && (total <= max_range);
+                }
+                nact = __popcll(vote(active));
             } while (nact > go);
         }
     }
