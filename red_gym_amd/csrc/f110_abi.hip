@@ -523,13 +523,13 @@ extern "C" int f110_set_tables(f110_handle *h, const double *sines, const double
 }
 
 // Publishes the device tables of a freshly built map in slot `slot` (both pipelines end here).
-static int finish_map(f110_handle *h, int slot, int H, int W, double res, double ox, double oy, double oc,
+static int finish_map(f110_handle *h, int slot, int H, int W, int Hp, size_t n_tiled, double res, double ox, double oy, double oc,
                       double os, double oob, unsigned lut_len)
 {
     f110_handle::MapSlot &sl = h->slots[slot];
     MapDev &m = sl.dev;
     m.cells = sl.d_cells; m.cells_far = sl.d_cells_far; m.lut = sl.d_lut; m.lut_lds = sl.d_lut_lds; m.dt = sl.d_dt;
-    m.H = H; m.W = W; m.row_bytes = map_row_bytes(W); m.cells_bytes = (unsigned)map_cells_bytes(H, W); m.res = res; m.rinv = 1.0 / res;
+    m.H = H; m.W = W; m.strip_bytes = (unsigned)Hp * 16u; m.cells_bytes = (unsigned)(n_tiled * sizeof(uint16_t)); m.res = res; m.rinv = 1.0 / res;
     m.ox = ox; m.oy = oy; m.oc = oc; m.os = os;
     m.wres = W * res; // width * resolution (laser_models.py:79)
     m.hres = H * res;
@@ -560,10 +560,10 @@ static int install_map(f110_handle *h, int slot, const double *dt, const uint32_
 {
     f110_handle::MapSlot &sl = h->slots[slot];
     const size_t n = (size_t)H * W;
-    // swizzled 8x8-block table, column W and the padding read as code 0 = "outside the map": see MapDev
-    const unsigned row_bytes = map_row_bytes(W);
-    const size_t n_tiled = map_cells_bytes(H, W) / sizeof(uint16_t);
-    std::vector<uint16_t> cells(n_tiled, 0), cells_far(n_tiled, 0);
+    // padded table (one border cell on every side), 8-column strips: see MapDev
+    const int Hp = map_rows_padded(H);
+    const size_t n_tiled = map_cells(H, W);
+    std::vector<uint16_t> cells(n_tiled, 0), cells_far(n_tiled, 0); // (border and padding: code 0 = LDS slot 0 = dt[-1, -1])
     // exact squared distance of every cell (ESC64: not of the form resolution*sqrt(integer))
     const uint64_t ESC64 = ~0ull;
     std::vector<uint64_t> d2v(n);
@@ -590,7 +590,7 @@ static int install_map(f110_handle *h, int slot, const double *dt, const uint32_
     std::vector<double> lut(n_lut, 0.0);
     for (size_t k = 0; k < n_lut && k < distinct.size(); k++) lut[k] = res * std::sqrt((double)distinct[k]);
     for (size_t i = 0; i < n; i++) {
-        const size_t t = cell_byte((unsigned)(i / W), (unsigned)(i % W), row_bytes) >> 1;
+        const size_t t = cell_elem((int)(i / W), (int)(i % W), Hp);
         size_t rank = CODE_ESC;
         if (d2v[i] != ESC64) rank = std::min<size_t>(std::lower_bound(distinct.begin(), distinct.end(), d2v[i]) - distinct.begin(), CODE_ESC);
         cells[t] = (uint16_t)cell_code((unsigned)rank);
@@ -613,11 +613,11 @@ static int install_map(f110_handle *h, int slot, const double *dt, const uint32_
     int rc = upload(&sl.d_lut, lut.data(), lut.size());
     if (rc) return rc;
     std::vector<double> lut_lds(LUT_LDS);
-    lut_lds[SLOT_OOB] = dt[n - 1];    // dt[-1, -1]: what code 0 (a look-up outside the map) reads
+    lut_lds[SLOT_OOB] = dt[n - 1];    // dt[-1, -1]: what code 0 (the border: a look-up outside the map) reads
     std::copy(lut.begin(), lut.begin() + LDS_RANKS, lut_lds.begin() + 1);
-    lut_lds[SLOT_FAR] = -0.0;         // the far marker (OFF_FAR cells take the second table): see cell_code
+    lut_lds[SLOT_FAR] = -0.0;         // the far marker (OFF_FAR cells take the second table): see MapDev
     if ((rc = upload(&sl.d_lut_lds, lut_lds.data(), lut_lds.size()))) return rc;
-    return finish_map(h, slot, H, W, res, ox, oy, oc, os, dt[n - 1], (unsigned)lut.size());
+    return finish_map(h, slot, H, W, Hp, n_tiled, res, ox, oy, oc, os, dt[n - 1], (unsigned)lut.size());
 }
 
 // ---------------------------------------------------------------- map pipeline on the device
@@ -675,8 +675,8 @@ static int install_map_occupancy_dev(f110_handle *h, int slot, const uint8_t *ma
 {
     f110_handle::MapSlot &sl = h->slots[slot];
     const size_t n = (size_t)H * W;
-    const unsigned row_bytes = map_row_bytes(W);
-    const size_t n_tiled = map_cells_bytes(H, W) / sizeof(uint16_t);
+    const int Hp = map_rows_padded(H);
+    const size_t n_tiled = map_cells(H, W);
     ON_DEVICE(h->cfg.device);
     HIP_TRY(hipDeviceSynchronize()); // the previous map may still be in use by enqueued steps
     hipStream_t st = nullptr;
@@ -716,7 +716,7 @@ static int install_map_occupancy_dev(f110_handle *h, int slot, const uint8_t *ma
     HIP_TRY(hipMalloc((void **)&sl.d_lut, (size_t)n_lut * sizeof(double)));
     HIP_TRY(hipMemsetAsync(sl.d_lut, 0, (size_t)n_lut * sizeof(double), st));
     hipLaunchKernelGGL(map_fill_border_kernel, dim3((unsigned)((n_tiled + 255) / 256)), dim3(256), 0, st, sl.d_cells, sl.d_cells_far, n_tiled);
-    hipLaunchKernelGGL(map_encode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d2, H, W, row_bytes, bits, prefix, res, sl.d_cells,
+    hipLaunchKernelGGL(map_encode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d2, H, W, Hp, bits, prefix, res, sl.d_cells,
                        sl.d_cells_far, sl.d_dt);
     hipLaunchKernelGGL(map_lut_kernel, dim3((n_words + 255) / 256), dim3(256), 0, st, bits, n_words, prefix, res, sl.d_lut, n_lut);
     HIP_TRY(hipGetLastError());
@@ -728,7 +728,7 @@ static int install_map_occupancy_dev(f110_handle *h, int slot, const uint8_t *ma
     lut_lds[SLOT_OOB] = oob;
     lut_lds[SLOT_FAR] = -0.0;
     if ((rc = upload(&sl.d_lut_lds, lut_lds.data(), lut_lds.size()))) return rc;
-    return finish_map(h, slot, H, W, res, ox, oy, oc, os, oob, n_lut);
+    return finish_map(h, slot, H, W, Hp, n_tiled, res, ox, oy, oc, os, oob, n_lut);
 }
 
 
@@ -748,9 +748,6 @@ static int check_map_args(f110_handle *h, const void *p, int H, int W, double re
 {
     if (!h || !p) return fail(F110_E_INVALID, "%s: null argument", who);
     if (H < 1 || W < 1 || (int64_t)(H + 10) * (W + 10) > (int64_t)1 << 30 || H + 10 >= (1 << 20)) return fail(F110_E_INVALID, "%s: bad map size %dx%d", who, H, W);
-    if (W > MAP_MAX_W)
-        return fail(F110_E_INVALID, "%s: map of %d columns; the cell table's descriptor addresses rows of at most %d (rotate the map by 90 degrees: "
-                    "its height may be up to 2^20 rows)", who, W, MAP_MAX_W);
     if (!(res > 0) || !std::isfinite(res)) return fail(F110_E_INVALID, "%s: bad resolution %g", who, res);
     return F110_OK;
 }

@@ -61,23 +61,19 @@ constexpr int REFILL_MIN_IDLE = F110_REFILL_MIN_IDLE; // refill the wave's beam 
 // values of the map, for k < LDS_RANKS = 1022 (squared distances are sums of two squares, so that reaches d2 ~ 3 900 =
 // 62 cells); OFF_FAR for larger ranks and for cells of a user table that are not resolution*sqrt(int) -- those re-read a
 // second table (u16 rank, 65535 = "use the fp64 table") in a rarely taken branch.
-// Code 0 is what a look-up OUTSIDE the map reads, and LDS slot 0 holds dt[-1,-1], the value the reference reads there
-// (laser_models.py:80-81,:103).
-//
-// Layout and addressing (round 5).  The table is read through a SWIZZLED structured buffer descriptor (GFX9: descriptor bit
-// 63; the swizzle element is a dword, INDEX_STRIDE 8; profiles/r05_swizzle_probe.txt shows gfx950 still implements it):
-// `buffer_load_ushort v, v[index:offset], s[rsrc], 0 idxen offen` with index = the cell's ROW and offset = 2 * its COLUMN
-// reads byte
-//     ((row >> 3) * stride + (col >> 1) * 4) * 8 + (row & 7) * 4 + (col & 1) * 2,        stride = bytes of one table row,
-// so one 128-B cache line holds an 8 x 8-cell block -- the 64 rays of a wave sample neighbouring points, and a gather over
-// such blocks touches fewer lines than one over rows (a row-major table measured ~40 L1 accesses per 64-lane gather) --
-// without ONE address instruction in the march loop, and the descriptor's range check (index >= num_records = H, which a
-// negative row is too once it is read as unsigned) answers 0 for a row outside the map: no clamp of the row either.
-// The hardware does NOT check the offset against the stride (same probe), so the column is clamped to [0, W] with one
-// v_min_u32 (a negative column read as unsigned is large: it lands on column W as well) and column W of every row holds
-// code 0.  Rounds 1-4 clamped both coordinates and formed the offset of an equivalent strip layout with six VALU
-// instructions per look-up; this is two (the clamp and the shift that scales the column to bytes).
-// stride is a 14-bit field: tables up to 8 184 columns; wider maps are refused at installation.
+// The table has a one-cell BORDER on every side holding code 0, and LDS slot 0 holds dt[-1,-1]: the reference's
+// out-of-bounds read (laser_models.py:80-81,:103) becomes an ordinary lookup of a clamped index -- no bounds compare, no
+// select in the march loop (the loaded value addresses the ds_read directly).
+// The far marker's LDS slot holds -0.0: as a distance it is an exact no-op (total += -0.0, x += -0.0 * c) that ends the ray's
+// march (-0.0 > eps is false); the wave looks at the sign of its parked lanes' last distance once per refill, not once per look-up.
+// Layout: 8-column strips, map cell (r, c), r in -1..H, c in -1..W, at [(c >> 3) + 1][r + 1][c & 7] (arithmetic
+// shift: the left border column is the last column of strip 0), so one 128-B cache line holds an 8x8-cell block.  The 64 rays of a wave sample neighbouring
+// points, so a gather touches fewer lines than with a row-major table (which measured
+// ~40 L1 accesses per 64-lane gather and made the kernel L1-tag-rate bound), and the byte
+// offset is two shift-adds and one multiply-add: (c >> 3) * (strip_bytes - 16) + (c << 1) + (r << 4) + strip_bytes + 16.
+// (Round 5 tried to have the address unit form an equivalent layout -- a swizzled structured descriptor, index = row, offset =
+// 2 * column, the descriptor's range check as the row clamp: two VALU instructions instead of six -- and it is exact and 26 %
+// slower: an `idxen` load merges at most two lanes per access, profiles/r05_swizzle_probe.txt.)
 #ifndef F110_LUT_LDS
 #define F110_LUT_LDS 1024
 #endif
@@ -86,25 +82,18 @@ constexpr unsigned SLOT_OOB = 0, SLOT_FAR = LUT_LDS - 1; // slot 0: dt[-1,-1]; s
 constexpr unsigned LDS_RANKS = LUT_LDS - 2;
 constexpr unsigned OFF_FAR = 8 * SLOT_FAR;
 constexpr unsigned CODE_ESC = 65535;                    // second table: read the fp64 table instead
-constexpr int MAP_MAX_W = 8184;                         // (W + 1 rounded up to 8 columns) * 2 B <= the 14-bit stride field
-// the far marker's LDS slot holds -0.0: as a distance it is an exact no-op (total += -0.0, x += -0.0 * c) that ends the ray's
-// march (-0.0 > eps is false); the wave looks at the sign of its parked lanes' last distance once per refill, not once per look-up
 __host__ __device__ inline unsigned cell_code(unsigned rank) { return rank < LDS_RANKS ? 8u * (rank + 1u) : OFF_FAR; }
-__host__ __device__ inline unsigned map_row_bytes(int W) { return (unsigned)(((W + 1 + 7) >> 3) << 3) * 2u; }
-__host__ __device__ inline size_t map_cells_bytes(int H, int W) { return (size_t)((H + 7) >> 3) * 8u * map_row_bytes(W); }
-// byte offset of cell (r, c), 0 <= r < H, 0 <= c <= W, in the swizzled table (what the address unit forms from index r, offset 2c)
-__host__ __device__ inline size_t cell_byte(unsigned r, unsigned c, unsigned row_bytes)
-{
-    return ((size_t)(r >> 3) * row_bytes + (size_t)(c >> 1) * 4u) * 8u + (r & 7u) * 4u + (c & 1u) * 2u;
-}
-
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// geometry of the padded strip table
+__host__ __device__ inline int map_rows_padded(int H) { return ((H + 2 + 7) >> 3) << 3; }
+__host__ __device__ inline size_t map_cells(int H, int W) { return (size_t)((W >> 3) + 2) * map_rows_padded(H) * 8; } // strip 0 only holds the left border column
+// element index of map cell (r, c), -1 <= r <= H, -1 <= c <= W
+__host__ __device__ inline size_t cell_elem(int r, int c, int Hp) { return ((size_t)((c >> 3) + 1) * Hp + (size_t)(r + 1)) * 8 + (size_t)(c & 7); }
 
 struct MapDev {
-    const uint16_t *cells;  // swizzled table of LDS byte offsets (see above): H rows (rounded up to 8) of row_bytes
+    const uint16_t *cells;  // padded strips [(W >> 3) + 2][Hp][8] of LDS byte offsets
     const uint16_t *cells_far; // same layout: rank (<= 65534) of the cells marked OFF_FAR, 65535 = fp64 table
     unsigned cells_bytes;
-    unsigned row_bytes;     // stride of the descriptor: (W + 1 rounded up to 8) * 2
+    unsigned strip_bytes;   // Hp * 16, Hp = H + 2 rounded up to a multiple of 8
     const double *lut;      // [lut_len <= 65535] resolution*sqrt(d2_k), indexed by rank k
     const double *lut_lds;  // [LUT_LDS] image staged in LDS: dt[-1,-1], lut[0..LDS_RANKS-1], -0.0
     const double *dt;       // [H*W] exact fp64 distance table (escape path, rarely touched)
@@ -113,42 +102,26 @@ struct MapDev {
     unsigned lut_len;       // entries of lut
 };
 
-// swizzled structured descriptor of a cell table: word 1 = base[47:32] | stride << 16 | swizzle enable (bit 31), word 2 =
-// num_records (rows), word 3 = data format 32 (as the raw descriptors of this library) with INDEX_STRIDE 0 (= 8 records).
-// Bits 19-20 of word 3 are NOT an element size on GFX9 (USER_VM_ENABLE / MODE: setting them faults).
-__device__ inline u32x4 make_cells_rsrc(const uint16_t *base, unsigned row_bytes, int rows)
-{
-    const unsigned long long a = (unsigned long long)base;
-    u32x4 r;
-    r.x = (unsigned)a;
-    r.y = ((unsigned)(a >> 32) & 0xffffu) | (row_bytes << 16) | 0x80000000u;
-    r.z = (unsigned)rows;
-    r.w = 0x00020000u;
-    return r;
-}
-
-// one look-up of the cell table: the load and its wait in one statement (the compiler does not count an asm load)
-__device__ inline unsigned load_cell(const u32x4 &rsrc, int row, unsigned col2)
-{
-    unsigned v;
-    const unsigned long long io = (unsigned long long)(unsigned)row | ((unsigned long long)col2 << 32);
-    asm volatile("buffer_load_ushort %0, %1, %2, 0 idxen offen\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(io), "s"(rsrc));
-    return v;
-}
-
-// device-side view of MapDev with the cell table behind its descriptor
+// device-side view of MapDev with the cell table behind a buffer resource descriptor
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 struct MapView {
-    u32x4 cells_rsrc;
+    __amdgpu_buffer_rsrc_t cells_rsrc;
+    u32x4 cells_words;   // the same descriptor as four words (an asm statement's operand)
+    unsigned row_bias, strip_m16; // row_bias = strip_bytes + 16, strip_m16 = strip_bytes - 16
     const MapDev *desc;  // rare paths (far cells, escape cells) re-read their table pointers from the descriptor:
                          // pointers that need not be kept in scalar registers across the march loop
     int H, W;
     double res, rinv, ox, oy, oc, os, wres, hres;
     double nox, noy; // -ox * rinv, -oy * rinv (exact when rinv is a power of two)
-    F110_BOUNDS_ONLY(uint32_t *err = nullptr;)
+    F110_BOUNDS_ONLY(uint32_t *err = nullptr; unsigned cells_bytes = 0;)
     __device__ void init(const MapDev &m)
     {
-        cells_rsrc = make_cells_rsrc(m.cells, m.row_bytes, m.H);
-        desc = &m; H = m.H; W = m.W; res = m.res; rinv = m.rinv;
+        F110_BOUNDS_ONLY(cells_bytes = m.cells_bytes;)
+        cells_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(m.cells), 0, (int)m.cells_bytes, 0x00020000);
+        cells_words.x = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)m.cells);
+        cells_words.y = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)m.cells >> 32) & 0xffffu);
+        cells_words.z = __builtin_amdgcn_readfirstlane(m.cells_bytes); cells_words.w = __builtin_amdgcn_readfirstlane(0x00020000u);
+        row_bias = m.strip_bytes + 16u; strip_m16 = m.strip_bytes - 16u; desc = &m; H = m.H; W = m.W; res = m.res; rinv = m.rinv;
         ox = m.ox; oy = m.oy; oc = m.oc; os = m.os; wres = m.wres; hres = m.hres;
         nox = -m.ox * m.rinv; noy = -m.oy * m.rinv;
     }
@@ -167,7 +140,7 @@ struct ScanDev {
 // resolution is a power of two, so q = x_rot * (1/res) IS the reference's quotient and
 // "x_rot < 0 or x_rot >= width*res" (:79) is exactly "floor(q) outside [0, W)".
 // laser_models.py:71-84 (xy_2_rc): the cell (column ci, row ri) of a point, un-clamped (a saturating conversion: any value
-// outside [0, W) x [0, H) means "out of bounds", which dist_lookup maps onto the reference's dt[-1, -1] read).
+// outside [0, W) x [0, H) means "out of bounds", which cell_offset maps onto the table's border = the reference's dt[-1, -1] read).
 template <bool IDENT, bool POW2>
 __device__ inline void cell_index(const MapView &m, double x, double y, int &ci, int &ri)
 {
@@ -186,7 +159,7 @@ __device__ inline void cell_index(const MapView &m, double x, double y, int &ci,
         qy = yr * m.rinv;
     }
     const double fx = floor(qx), fy = floor(qy);
-    ci = (int)fx; ri = (int)fy; // saturating conversion; the column clamp / the descriptor's row check finish the job
+    ci = (int)fx; ri = (int)fy; // saturating conversion; the clamp in cell_offset finishes the job
     if (!POW2) {
         // int(x_rot/resolution) and the bounds test need the IEEE quotient: x_rot*(1/res) is
         // within ~2e-12 of it, so only quotients within 1e-9 of an integer (where truncation
@@ -203,6 +176,22 @@ __device__ inline void cell_index(const MapView &m, double x, double y, int &ci,
     }
 }
 
+// byte offset of the cell under (column ci, row ri) in the strip table: both clamped onto the border
+__device__ inline unsigned cell_offset(const MapView &m, int ci, int ri)
+{
+    const int cc = med3_i32(ci, -1, m.W);      // column -1..W (both ends are border cells)
+    const int rr = med3_i32(ri, -1, m.H);      // row -1..H
+    // strip (cc >> 3) + 1 (arithmetic shift: column -1 is the last column of strip 0), 16 bytes per row inside a strip.  The
+    // +1 strip and the +1 border row ride in the constant of the shift-add (`row_bias` = strip_bytes + 16, a multiple of 16),
+    // so no add is spent on the padding and the offset never goes negative; asm so that the constant is not re-associated
+    // into a trailing add.  (c >> 3) * S + (c & 7) * 2 == (c >> 3) * (S - 16) + c * 2: no masking of the column bits needed
+    unsigned row16;
+    asm("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(row16) : "v"(rr), "s"(m.row_bias));
+    unsigned rc;
+    asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(rc) : "v"(cc), "v"(row16));
+    return (unsigned)(__mul24(cc >> 3, (int)m.strip_m16) + (int)rc);
+}
+
 // One table look-up (laser_models.py:56-104 distance_transform): the value of the cell under (x, y), or -0.0 when the cell
 // carries the far marker (dist_lookup_far finishes those).  The caller runs it under the EXEC mask of the rays that are
 // still marching: a finished ray issues nothing.
@@ -211,18 +200,12 @@ __device__ inline double dist_lookup(const MapView &m, const double *lds_lut, do
 {
     int ci, ri;
     cell_index<IDENT, POW2>(m, x, y, ci, ri);
-    // column: [0, W) as it is, everything else (negative columns are large unsigned values) -> column W, which holds code 0;
-    // row: the descriptor's range check (index >= H) answers code 0 by itself
-    const unsigned col2 = min((unsigned)ci, (unsigned)m.W) << 1;
+    const unsigned off = cell_offset(m, ci, ri);
+    // buffer load: 32-bit per-lane offset against a scalar descriptor
+    unsigned code = (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(m.cells_rsrc, (int)off, 0, 0);
 #if defined(F110_BOUNDS)
-    F110_BCHK((size_t)col2 + 2u <= m.desc->row_bytes, BT_LUT_CODE, m.err);
-    const bool row_in = (unsigned)ri < (unsigned)m.H;
-    F110_BCHK(!row_in || cell_byte((unsigned)ri, col2 >> 1, m.desc->row_bytes) + 2u <= m.desc->cells_bytes, BT_LUT_CODE, m.err);
-#endif
-    unsigned code = load_cell(m.cells_rsrc, ri, col2);
-#if defined(F110_BOUNDS)
+    F110_BCHK(off + 2u <= m.cells_bytes, BT_LUT_CODE, m.err);
     F110_BCHK(code <= OFF_FAR && (code & 7u) == 0u, BT_LUT_CODE, m.err);
-    F110_BCHK(row_in || code == 0u, BT_LUT_CODE, m.err); // (the range check's answer)
     code = code <= OFF_FAR ? (code & ~7u) : 0u;
 #endif
     // the loaded value IS the LDS byte offset of the distance: one ds_read_b64
@@ -237,17 +220,21 @@ __device__ inline double dist_lookup_far(const MapView &m, double x, double y)
 {
     int ci, ri;
     cell_index<IDENT, POW2>(m, x, y, ci, ri);
+    unsigned off = cell_offset(m, ci, ri);
     const MapDev *dp = m.desc;
     asm volatile("" : "+s"(dp)); // opaque: the loads below stay here instead of being hoisted to the kernel entry
-    // (a cell with the far marker is inside the map: 0 <= ri < H, 0 <= ci < W)
-    bool ok = (unsigned)ri < (unsigned)m.H && (unsigned)ci < (unsigned)m.W;
-    F110_BCHK(ok, BT_CELLS_FAR, m.err);
-    if (!ok) return dp->oob;
-    unsigned rank = *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(dp->cells_far) + cell_byte((unsigned)ri, (unsigned)ci, dp->row_bytes));
+#if defined(F110_BOUNDS)
+    F110_BCHK(off + 2u <= dp->cells_bytes, BT_CELLS_FAR, m.err);
+    if (off + 2u > dp->cells_bytes) off = 0u;
+#endif
+    unsigned rank = *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(dp->cells_far) + (size_t)off);
+    const bool inside = (unsigned)ri < (unsigned)m.H && (unsigned)ci < (unsigned)m.W; // (a border cell never carries the far marker)
 #if defined(F110_BOUNDS)
     F110_BCHK(rank == CODE_ESC || rank < dp->lut_len, BT_LUT_RANK, m.err);
     if (rank != CODE_ESC && rank >= dp->lut_len) rank = 0u;
+    F110_BCHK(rank != CODE_ESC || inside, BT_DT, m.err);
 #endif
+    if (rank == CODE_ESC && !inside) return dp->oob;
     return (rank != CODE_ESC) ? dp->lut[rank] : dp->dt[(size_t)(unsigned)ri * (unsigned)m.W + (unsigned)ci];
 }
 __device__ inline bool is_far_marker(double d) { return __double2hiint(d) == (int)0x80000000; } // -0.0 (no table value is negative)
@@ -289,6 +276,63 @@ __device__ inline int beam_theta_index(unsigned long long T0, double t0w, int b,
         idx = (int)tt;
     }
     return idx;
+}
+
+// The march phase of a wave for a map whose origin is not rotated and whose resolution is a power of two (cell_index's
+// one-fma form), written out: every ray that is still marching takes table look-ups (laser_models.py:129-142) until at most
+// `go` rays are left.  The loop runs under the EXEC mask of the marching rays and narrows it with v_cmpx as rays finish, so a
+// finished ray issues no look-up, keeps its total and costs no select; what remains per iteration is
+//   2 fma + 2 floor + 2 cvt (the cell), 2 med3 + 2 shift-add + shift + mad (its byte offset), the look-up (buffer_load_ushort ->
+//   ds_read_b64), total += d, x += d * c, y += d * s (5, contraction off), 2 v_cmpx          = 19 VALU, 5 SALU
+// against 21 VALU + 11 SALU for the compiler's branch-free form of round 4 (a select that parked finished lanes on an
+// out-of-range offset, a compare for the far marker, the active mask kept in SGPRs by s_and / s_andn2 / s_or).
+//   am: in, the rays marching; out, the rays still marching.  nlook += look-ups made.  d: every lane's last table value.
+// The loads and their waits are inside the statement (the compiler does not count an asm load).  The LDS LUT must sit at LDS
+// address 0 (scan_kernel checks it).
+__device__ inline void march_ident_pow2(const MapView &m, double &x, double &y, double &total, double &d, double c, double s,
+                                        double eps, double max_range, unsigned long long &am, int go, unsigned &nlook, int &nact)
+{
+    unsigned long long sx;
+    double q0, q1;
+    int t0, t1, t2;
+    asm volatile(
+        "s_mov_b64 %[sx], exec\n\t"
+        "s_mov_b64 exec, %[am]\n"
+        "1:\n\t"
+        "s_add_u32 %[nl], %[nl], %[na]\n\t"
+        "v_fma_f64 %[q0], %[rinv], %[x], %[nox]\n\t"
+        "v_fma_f64 %[q1], %[rinv], %[y], %[noy]\n\t"
+        "v_floor_f64 %[q0], %[q0]\n\t"
+        "v_floor_f64 %[q1], %[q1]\n\t"
+        "v_cvt_i32_f64 %[t0], %[q0]\n\t"
+        "v_cvt_i32_f64 %[t1], %[q1]\n\t"
+        "v_med3_i32 %[t0], %[t0], -1, %[W]\n\t"
+        "v_med3_i32 %[t1], %[t1], -1, %[H]\n\t"
+        "v_lshl_add_u32 %[t1], %[t1], 4, %[rb]\n\t"
+        "v_ashrrev_i32 %[t2], 3, %[t0]\n\t"
+        "v_lshl_add_u32 %[t1], %[t0], 1, %[t1]\n\t"
+        "v_mad_i32_i24 %[t2], %[t2], %[sm], %[t1]\n\t"
+        "buffer_load_ushort %[t2], %[t2], %[rsrc], 0 offen\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        "ds_read_b64 %[d], %[t2]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_add_f64 %[tot], %[tot], %[d]\n\t"
+        "v_mul_f64 %[q0], %[c], %[d]\n\t"
+        "v_mul_f64 %[q1], %[s], %[d]\n\t"
+        "v_add_f64 %[x], %[x], %[q0]\n\t"
+        "v_add_f64 %[y], %[y], %[q1]\n\t"
+        "v_cmpx_lt_f64 vcc, %[eps], %[d]\n\t"
+        "v_cmpx_ge_f64 vcc, %[mr], %[tot]\n\t"
+        "s_bcnt1_i32_b64 %[na], exec\n\t"
+        "s_cmp_gt_i32 %[na], %[go]\n\t"
+        "s_cbranch_scc1 1b\n\t"
+        "s_mov_b64 %[am], exec\n\t"
+        "s_mov_b64 exec, %[sx]"
+        : [x] "+v"(x), [y] "+v"(y), [tot] "+v"(total), [d] "+v"(d), [am] "+s"(am), [nl] "+s"(nlook), [na] "+s"(nact),
+          [sx] "=&s"(sx), [q0] "=&v"(q0), [q1] "=&v"(q1), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2)
+        : [c] "v"(c), [s] "v"(s), [nox] "v"(m.nox), [noy] "v"(m.noy), [rinv] "s"(m.rinv), [W] "s"(m.W), [H] "s"(m.H),
+          [rb] "s"(m.row_bias), [sm] "s"(m.strip_m16), [rsrc] "s"(m.cells_words), [eps] "s"(eps), [mr] "s"(max_range), [go] "s"(go)
+        : "vcc", "scc", "memory");
 }
 
 struct ScanArgs {
@@ -365,8 +409,11 @@ template <bool IDENT, bool POW2, int SM>
 __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel(ScanArgs a)
 {
     constexpr bool STEP = SM >= 1;
-    __shared__ __attribute__((aligned(16))) double s_lut[LUT_LDS];
-    __shared__ int s_chunk0[MAX_CHUNKS];
+    // ONE LDS object, the LUT first: march_ident_pow2 addresses the LUT by the cell codes alone, i.e. the LUT sits at LDS
+    // address 0 (the kernel has no other LDS variable; every parity test would fail otherwise)
+    __shared__ struct __attribute__((aligned(16))) { double lut[LUT_LDS]; int chunk0[MAX_CHUNKS]; } s_mem;
+    double *const s_lut = s_mem.lut;
+    int *const s_chunk0 = s_mem.chunk0;
     // the same argument block addressed through the kernarg segment (ScanArgs is the only kernel argument): rarely
     // needed fields are re-read through it where they are used instead of being held in SGPRs for the whole kernel
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -596,6 +643,17 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
 #endif
 #if defined(F110_TIMELINE)
             if (go == 0 && !tl_dry) { unsigned long long t = wall_clock64(); asm volatile("" : "+v"(t)); if (lane == 0) s_tl[wave][1] = t; tl_dry = true; tl_wit_dry = tl_wit; }
+#endif
+#if !defined(F110_TIMELINE) && !defined(F110_BOUNDS)
+            if (IDENT && POW2) {
+                unsigned long long am = vote(active);
+                unsigned nl = __builtin_amdgcn_readfirstlane(nlook);
+                int na = __builtin_amdgcn_readfirstlane(nact);
+                march_ident_pow2(mv, x, y, total, d, c, s, eps, max_range, am, __builtin_amdgcn_readfirstlane(go), nl, na);
+                nlook = nl; nact = na;
+                active = ((am >> lane) & 1ull) != 0ull;
+                continue;
+            }
 #endif
             do {
 #if defined(F110_TIMELINE)

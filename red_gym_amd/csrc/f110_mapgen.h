@@ -147,8 +147,8 @@ __device__ inline unsigned d2_rank(const unsigned *bits, const unsigned *word_pr
     return word_prefix[v >> 5] + __popc(bits[v >> 5] & ((1u << (v & 31)) - 1u));
 }
 
-// cell codes (swizzled 8x8-block layout, see MapDev), second rank table and the fp64 distance table
-__global__ __launch_bounds__(256) void map_encode_kernel(const unsigned *d2, int H, int W, unsigned row_bytes, const unsigned *bits,
+// cell codes (strip layout with border, see MapDev), second rank table and the fp64 distance table
+__global__ __launch_bounds__(256) void map_encode_kernel(const unsigned *d2, int H, int W, int Hp, const unsigned *bits,
                                                          const unsigned *word_prefix, double res, uint16_t *cells,
                                                          uint16_t *cells_far, double *dt)
 {
@@ -156,18 +156,17 @@ __global__ __launch_bounds__(256) void map_encode_kernel(const unsigned *d2, int
     if (i >= (size_t)H * W) return;
     const unsigned v = d2[i];
     const unsigned rank = d2_rank(bits, word_prefix, v);
-    const size_t t = cell_byte((unsigned)(i / W), (unsigned)(i % W), row_bytes) >> 1;
+    const size_t t = cell_elem((int)(i / W), (int)(i % W), Hp);
     cells[t] = (uint16_t)cell_code(rank);
     cells_far[t] = (uint16_t)(rank < CODE_ESC ? rank : CODE_ESC);
     dt[i] = res * sqrt((double)v);
 }
 
-// everything that is not a map cell (column W and the padding columns of every row, the padding rows) reads as code 0 = "outside"
 __global__ __launch_bounds__(256) void map_fill_border_kernel(uint16_t *cells, uint16_t *cells_far, size_t n)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    cells[i] = 0;
+    cells[i] = 0; // the border and the padding: code 0 = LDS slot 0 = dt[-1, -1]
     cells_far[i] = 0;
 }
 
