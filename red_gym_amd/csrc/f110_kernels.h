@@ -50,7 +50,7 @@ constexpr int TL_MAX_WAVES = 8; // (diagnostics builds: per-wave stamps of a wor
 #define F110_SCAN_WAVES 2
 #endif
 #ifndef F110_REFILL_MIN_IDLE
-#define F110_REFILL_MIN_IDLE 40
+#define F110_REFILL_MIN_IDLE 44
 #endif
 constexpr int SCAN_WAVES = F110_SCAN_WAVES;   // cars per workgroup (one wavefront each)
 constexpr int SCAN_THREADS = SCAN_WAVES * WAVE;
@@ -335,6 +335,75 @@ __device__ inline void march_ident_pow2(const MapView &m, double &x, double &y, 
         : "vcc", "scc", "memory");
 }
 
+// The same loop for a car that is not absurdly far from its map (scan_kernel decides per car: |cell coordinates of the car| +
+// max_range / resolution + 2 below `march_fast_limit`; every look-up of a ray is made within max_range of the car, because the
+// march only continues while total <= max_range).  Two things become possible, both exact:
+//  * floor + int conversion by the MAGIC NUMBER: q + 1.5 * 2^52 rounded TOWARD MINUS INFINITY is floor(q) + 1.5 * 2^52 exactly (the
+//    sum's ulp is 1), and the low dword of that double is floor(q) as a two's complement int for |q| < 2^31: one v_add_f64 under
+//    round mode -inf (s_setreg on MODE's f64 rounding field around the pair; the fma that forms q and the sums of the march stay
+//    round-to-nearest) instead of v_floor_f64 + v_cvt_i32_f64;
+//  * no clamp of the COLUMN: a column outside [-8, W + 8) forms an offset outside the table (negative ones wrap to large
+//    unsigned values), which the descriptor's range check answers with 0 = the border's code; the columns in between lie in the
+//    border strips.  That needs (c >> 3) * strip_bytes below 2^31, which the limit guarantees.  (The row still needs its clamp:
+//    a row beyond the strip would land in the neighbouring strip.)
+// 16 VALU + 6 SALU per iteration.  The magic sums and the products live in v[60:63]: an asm operand cannot name the low dword
+// of a register pair, so the statement uses those four registers by name and declares them clobbered.
+__device__ inline void march_ident_pow2_fast(const MapView &m, double &x, double &y, double &total, double &d, double c, double s,
+                                             double eps, double max_range, unsigned long long &am, int go, unsigned &nlook, int &nact)
+{
+    unsigned long long sx;
+    asm volatile(
+        "s_mov_b64 %[sx], exec\n\t"
+        "s_mov_b64 exec, %[am]\n"
+        "1:\n\t"
+        "s_add_u32 %[nl], %[nl], %[na]\n\t"
+        "v_fma_f64 v[60:61], %[rinv], %[x], %[nox]\n\t"
+        "v_fma_f64 v[62:63], %[rinv], %[y], %[noy]\n\t"
+#if defined(F110_X_NOMAGIC) // timing experiment
+        "v_floor_f64 v[60:61], v[60:61]\n\t"
+        "v_floor_f64 v[62:63], v[62:63]\n\t"
+        "v_cvt_i32_f64 v60, v[60:61]\n\t"
+        "v_cvt_i32_f64 v62, v[62:63]\n\t"
+#else
+        "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 2\n\t"      // f64 rounding: toward -inf
+        "v_add_f64 v[60:61], v[60:61], %[magic]\n\t"
+        "v_add_f64 v[62:63], v[62:63], %[magic]\n\t"
+        "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 0\n\t"      // back to nearest-even
+#endif
+#if defined(F110_X_PAD)
+        "v_mov_b32 v61, v61\n\tv_mov_b32 v61, v61\n\tv_mov_b32 v61, v61\n\t"
+#endif
+        "v_med3_i32 v62, v62, -1, %[H]\n\t"
+        "v_ashrrev_i32 v61, 3, v60\n\t"
+        "v_lshl_add_u32 v62, v62, 4, %[rb]\n\t"
+        "v_lshl_add_u32 v62, v60, 1, v62\n\t"
+        "v_mad_i32_i24 v61, v61, %[sm], v62\n\t"
+        "buffer_load_ushort v61, v61, %[rsrc], 0 offen\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        "ds_read_b64 %[d], v61\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_add_f64 %[tot], %[tot], %[d]\n\t"
+        "v_mul_f64 v[60:61], %[c], %[d]\n\t"
+        "v_mul_f64 v[62:63], %[s], %[d]\n\t"
+        "v_add_f64 %[x], %[x], v[60:61]\n\t"
+        "v_add_f64 %[y], %[y], v[62:63]\n\t"
+        "v_cmpx_lt_f64 vcc, %[eps], %[d]\n\t"
+        "v_cmpx_ge_f64 vcc, %[mr], %[tot]\n\t"
+        "s_bcnt1_i32_b64 %[na], exec\n\t"
+        "s_cmp_gt_i32 %[na], %[go]\n\t"
+        "s_cbranch_scc1 1b\n\t"
+        "s_mov_b64 %[am], exec\n\t"
+        "s_mov_b64 exec, %[sx]"
+        : [x] "+v"(x), [y] "+v"(y), [tot] "+v"(total), [d] "+v"(d), [am] "+s"(am), [nl] "+s"(nlook), [na] "+s"(nact), [sx] "=&s"(sx)
+        : [c] "v"(c), [s] "v"(s), [nox] "v"(m.nox), [noy] "v"(m.noy), [rinv] "s"(m.rinv), [H] "s"(m.H),
+          [rb] "s"(m.row_bias), [sm] "s"(m.strip_m16), [rsrc] "s"(m.cells_words), [eps] "s"(eps), [mr] "s"(max_range), [go] "s"(go),
+          [magic] "s"(6755399441055744.0)
+        : "vcc", "scc", "memory", "v60", "v61", "v62", "v63");
+}
+// the largest |cell coordinate| a look-up of the fast march may have: (c >> 3) * strip_bytes stays below 2^31 with room to
+// spare, and far inside the magic number's 2^31 (a NaN or infinite pose fails the test and takes the clamped loop)
+__device__ inline double march_fast_limit(const MapView &m) { return (double)((0x7fffffffu / (m.row_bias + 16u)) * 8u) - 64.0; }
+
 struct ScanArgs {
     const MapDev *maps;         // dev [K] map descriptors
     const int32_t *env_map;     // dev [B] map of every env, or NULL (all envs on maps[0]); the cars of one
@@ -548,6 +617,7 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
 #endif
 #if defined(F110_TIMELINE)
     unsigned tl_wit = 0, tl_wit_dry = 0; // march iterations of the wave so far / when its queue ran dry
+    unsigned tl_refills = 0, tl_phases = 0; // refill phases in which beams were taken / passes of the outer loop
 #endif
     unsigned nlook = (unsigned)nbl; // the reference reads the table once per beam before marching
     if (!(d0 > eps && d0 <= max_range)) {
@@ -571,6 +641,12 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
 #if defined(F110_TIMELINE)
         bool tl_dry = false;
 #endif
+        // (wave-uniform) may this car's rays take the fast march?  Every look-up lies within max_range of the car.
+        bool fast = false;
+        if (IDENT && POW2) {
+            const double reach = max_range * mv.rinv + 2.0, lim = march_fast_limit(mv);
+            fast = fabs(__builtin_fma(px, mv.rinv, mv.nox)) + reach < lim && fabs(__builtin_fma(py, mv.rinv, mv.noy)) + reach < lim;
+        }
         int next = 0;           // wave-uniform: next unassigned slot of the beam order
         bool active = false;
         int beam = -1;          // beam whose result `total` holds (-1: none)
@@ -595,6 +671,10 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
             // ---- refill phase: idle lanes finish their beam and take the next one ----
             const unsigned long long idle = vote(!active);
             const int nidle = __popcll(idle);
+#if defined(F110_TIMELINE)
+            tl_phases++;
+            if (next < nbl) tl_refills++;
+#endif
             if (!active) {
                 // all independent loads first (one memory round trip).  The noise entry is fetched
                 // for the beam being TAKEN and carried in registers until the beam is finished: idle lanes take
@@ -647,10 +727,8 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
 #if !defined(F110_TIMELINE) && !defined(F110_BOUNDS)
             if (IDENT && POW2) {
                 unsigned long long am = vote(active);
-                unsigned nl = __builtin_amdgcn_readfirstlane(nlook);
-                int na = __builtin_amdgcn_readfirstlane(nact);
-                march_ident_pow2(mv, x, y, total, d, c, s, eps, max_range, am, __builtin_amdgcn_readfirstlane(go), nl, na);
-                nlook = nl; nact = na;
+                if (fast) march_ident_pow2_fast(mv, x, y, total, d, c, s, eps, max_range, am, go, nlook, nact);
+                else march_ident_pow2(mv, x, y, total, d, c, s, eps, max_range, am, go, nlook, nact);
                 active = ((am >> lane) & 1ull) != 0ull;
                 continue;
             }
@@ -680,7 +758,9 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
     if (ra->timeline && lane == 0) {
         unsigned long long *tl = ra->timeline + (size_t)wid * 4;
         // {start, queue ran dry (or first rays), end}; car << 8 | part | wpc << 40 | iterations after the queue ran dry << 44
-        tl[0] = s_tl[wave][0]; tl[1] = s_tl[wave][1]; tl[2] = tl_end;
+        // (time stamps are 100 MHz ticks: their top 16 bits are free; they carry the wave's march iterations and its refills)
+        tl[0] = s_tl[wave][0] | ((unsigned long long)min(tl_wit, 0xffffu) << 48); tl[1] = s_tl[wave][1] | ((unsigned long long)min(tl_phases, 0xffffu) << 48);
+        tl[2] = tl_end | ((unsigned long long)min(tl_refills, 0xffffu) << 48);
         tl[3] = ((unsigned long long)car << 8) | (unsigned)part | ((unsigned long long)wpc << 40) | ((unsigned long long)min(tl_wit - tl_wit_dry, 0xfffffu) << 44);
     }
 #endif

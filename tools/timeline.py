@@ -44,6 +44,12 @@ N = 1 << 18
 buf = np.zeros((N, 4), dtype=np.uint64)
 assert lib.f110_debug_timeline(buf.ctypes.data_as(C.c_void_p), N) == 0
 buf = buf[buf[:, 0] != 0]
+# the top 16 bits of the three stamps carry counts: march iterations, passes of the outer loop, refill phases (beams taken)
+M48 = np.uint64((1 << 48) - 1)
+march_it = (buf[:, 0] >> np.uint64(48)).astype(np.int64)
+phases = (buf[:, 1] >> np.uint64(48)).astype(np.int64)
+refills = (buf[:, 2] >> np.uint64(48)).astype(np.int64)
+buf[:, 0] &= M48; buf[:, 1] &= M48; buf[:, 2] &= M48
 t0 = buf[:, 0].min()
 start = (buf[:, 0] - t0).astype(np.float64) / 100.0   # 100 MHz ticks -> us
 ready = (buf[:, 1] - t0).astype(np.float64) / 100.0
@@ -52,6 +58,9 @@ end = (buf[:, 2] - t0).astype(np.float64) / 100.0
 wpc = ((buf[:, 3] >> np.uint64(40)) & np.uint64(0xf)).astype(np.int64)
 car = ((buf[:, 3] >> np.uint64(8)) & np.uint64(0xffffffff)).astype(np.int64)
 drain_it = (buf[:, 3] >> np.uint64(44)).astype(np.int64)
+ncars = len(set(car.tolist()))
+print('  per car (sum over its waves): march iterations %.1f, refill phases %.1f, passes of the outer loop %.1f; per wave: %.1f / %.1f / %.1f; %d cars, %d waves'
+      % (march_it.sum() / ncars, refills.sum() / ncars, phases.sum() / ncars, march_it.mean(), refills.mean(), phases.mean(), ncars, len(buf)))
 print('%s envs, lib %s, stages=%r: %d waves, launch ends at %.1f us after the first wave starts' % (B, os.path.basename(os.environ.get('F110_LIB', 'default')), a.stages, len(buf), end.max()))
 pc = lambda x: ' '.join('%.1f' % v for v in np.percentile(x, [0, 10, 50, 90, 99, 100]))  # noqa: E731
 print('  wave start      p0/10/50/90/99/100: ' + pc(start))
