@@ -258,7 +258,10 @@ __device__ inline double fmod_small(double t, double td)
 // the fraction is within 1e-7 of 0 or 1 -- then this lane replays the recurrence exactly.
 // The index is NOT wrapped: the {cos, sin} table is stored `cs_reps` times back to back
 // (wrapping subtracts theta_dis exactly, so entry idx and idx - theta_dis are the same).
-__device__ inline int beam_theta_index(unsigned long long T0, double t0w, int b, const ScanDev &s)
+// `guard2`: twice the guard band in units of 2^-32, less one (860 = 2 x 1e-7), or 0xffffffff when T0 is not a valid fixed-point
+// start (NaN / infinite yaw): then every lane replays.  For a valid T0 the un-wrapped index stays inside the repeated table
+// (upload_cs sizes it), so no per-lane compare against its length -- and no re-read of that length in every refill -- is needed.
+__device__ inline int beam_theta_index(unsigned long long T0, double t0w, int b, const ScanDev &s, unsigned guard2)
 {
     const unsigned inc_lo = (unsigned)s.inc_fx, inc_hi = (unsigned)(s.inc_fx >> 32);
     unsigned long long t = (unsigned long long)(unsigned)b * inc_lo + T0;    // v_mad_u64_u32
@@ -266,7 +269,7 @@ __device__ inline int beam_theta_index(unsigned long long T0, double t0w, int b,
     const unsigned lo = (unsigned)t;
     int idx = (int)(hi >> 8);
     const unsigned frac = __builtin_amdgcn_alignbit(hi, lo, 8);             // top 32 fraction bits
-    if (__builtin_expect(frac + 430u < 860u || idx >= s.cs_len, 0)) {        // within 1e-7 of an integer
+    if (__builtin_expect(frac + 430u <= guard2, 0)) {                         // within 1e-7 of an integer
         const double td = (double)s.theta_dis;
         double tt = t0w;
         for (int j = 0; j < b; j++) {
@@ -582,7 +585,8 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
         F110_BCHK((unsigned)i < (unsigned)nb, BT_SCAN_STORE, rare->dev_err);
         if ((unsigned)i >= (unsigned)nb) return;
 #endif
-        double v = __builtin_fmin(tot, max_range); // :143-144 (a NaN total, i.e. a NaN pose, also clamps)
+        double v; // :143-144 min(total, max_range) (a NaN total, i.e. a NaN pose, also clamps: v_min_f64 returns the other operand)
+        asm("v_min_f64 %0, %1, %2" : "=v"(v) : "v"(tot), "s"(max_range)); // (fmin() would first quieten both operands: two more instructions)
         if (STEP) v += nzv;
         // Streaming (non-temporal) stores: the scan is written once and read by later kernels only; as ordinary stores the
         // 27 scattered store instructions of a car took their turn in the L1 beside the table look-ups, which are what bounds
@@ -636,7 +640,9 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
         t0w = fmod_small(t0w, td);
         while (t0w < 0) t0w += td;
         // 24.40 fixed point of t0w in [0, theta_dis); a NaN / out-of-range yaw falls to the slow path
-        const unsigned long long T0 = (t0w >= 0 && t0w < td) ? (unsigned long long)(t0w * 1099511627776.0) : ~0ull;
+        const bool t0_ok = t0w >= 0 && t0w < td;
+        const unsigned long long T0 = t0_ok ? (unsigned long long)(t0w * 1099511627776.0) : 0ull;
+        const unsigned guard2 = t0_ok ? 859u : 0xffffffffu;
 
 #if defined(F110_TIMELINE)
         bool tl_dry = false;
@@ -693,7 +699,7 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
 #endif
                 const double nsv = STEP ? *reinterpret_cast<const double *>(reinterpret_cast<const char *>(ns) + (size_t)((unsigned)b * 8u)) : 0.0;
                 const double nzv = nz;
-                int ti = beam_theta_index(T0, t0w, b, a.scan);
+                int ti = beam_theta_index(T0, t0w, b, a.scan, guard2);
 #if defined(F110_BOUNDS)
                 F110_BCHK((unsigned)ti < (unsigned)a.scan.cs_len, BT_CS_TABLE, rare->dev_err);
                 if ((unsigned)ti >= (unsigned)a.scan.cs_len) ti = 0;
@@ -701,9 +707,9 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
                 const double2 cs = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(a.scan.cs) + (size_t)((unsigned)ti * 16u)); // second round trip, overlapped with emit()
                 if (beam >= 0) emit(beam, total, nzv);
                 beam = -1;
+                c = cs.x; // (every idle lane: one that takes no beam never marches again, and the far look-ups are finished above)
+                s = cs.y;
                 if (take) {
-                    c = cs.x;
-                    s = cs.y;
                     x = px + d0 * c;
                     y = py + d0 * s;
                     total = d0;
