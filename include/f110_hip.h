@@ -203,10 +203,17 @@ int f110_edt_squared_dev(const uint8_t *free_mask_dev, int32_t height, int32_t w
  * generated slots produce what is missing (a one-wavefront kernel per slot; the table doubles when it must: cold path,
  * synchronises), host tables that are too short give F110_E_INVALID.  f110_noise_prefetch(h, rows) starts producing
  * ahead of time on the handle's own stream, beside the caller's work; a later f110_noise_ensure only waits for it.
- * Floor: when no car can read rows below `lo` any more (autoreset off and every car past them), f110_noise_set_floor
- * lets the table recycle them -- it is a ring, so a run of any length holds a window of rows in constant memory.
- * Lowering the floor again (a reset) re-produces the dropped rows from the seeds.  A car whose row lies outside
- * [floor, rows produced) sets F110_DEVERR_NOISE_WINDOW in the device error word instead of reading silently.
+ * Floor: when no car will read rows below `lo` in any step enqueued FROM NOW ON (autoreset off and, by the host's own step
+ * count, every car past them), f110_noise_set_floor(h, lo, stream) lets the table recycle them -- it is a ring, so a run of any
+ * length holds a window of rows in constant memory.  Steps already enqueued on `stream` may still read those rows: the call
+ * records an event there, and the next prefetch (which writes the recycled places from the handle's own stream) waits for it;
+ * so does a generator launch that f110_noise_ensure put on the caller's stream (both work on the same generator states).
+ * Lowering the floor again (a masked reset sends cars back to row 0 while others run on) re-produces the dropped rows in
+ * `stream` from the MARKS the generators leave every 64 rows -- one wavefront per slot and 64 rows, all at once; the generators
+ * stay where they are (round 4 rewound them to the seeds: ~15 us per row of the whole run).  The ring then spans floor .. rows
+ * produced, i.e. the ages of the youngest and the oldest car: rows x num_beams x 8 B per slot (20 000 steps: 173 MB per seed).
+ * A car whose row lies outside [floor, rows produced) sets F110_DEVERR_NOISE_WINDOW in the device error word instead of
+ * reading silently.
  * Launch epoch: the scan takes the table's base and size by value (a pointer chase per wave costs 0.9 % of the launch), so
  * a RE-ALLOCATION -- the ring too small for the rows between the floor and the fastest car: it doubles -- moves the launch
  * epoch like every other table change; the window of rows present (floor, rows produced) moves without it, behind a

@@ -111,6 +111,14 @@ struct f110_handle {
     hipStream_t noise_stream = nullptr; // the generator runs here, beside the caller's stream (f110_noise_prefetch)
     hipEvent_t noise_ev = nullptr;
     long long noise_pending_hi = 0;   // rows a prefetch in flight on noise_stream will have produced (0: none in flight)
+    // Ordering of the side stream behind the caller's: recorded on the caller's stream whenever the floor is raised (the steps
+    // enqueued so far may still read the rows below it, whose ring places the next prefetch recycles) and whenever a generator
+    // kernel is enqueued there (it reads and writes the same generator states); the next prefetch waits for it.
+    hipEvent_t order_ev = nullptr;
+    bool order_ev_set = false;
+    NoiseMark *d_marks = nullptr;     // [noise_slots][marks_cap] generator state at every 64th row (f110_noise.h NoiseMark)
+    long long marks_cap = 0;
+    int marks_slots = 0;
     struct Retired { void *ptr; hipEvent_t ev; };
     std::vector<Retired> retired;     // old noise tables, freed once the work that may read them has drained
     uint32_t *d_err = nullptr;        // device error word (f110_device_errors)
@@ -398,6 +406,8 @@ extern "C" void f110_destroy(f110_handle *h)
         if (p) (void)hipFree(p);
     for (auto &r : h->retired) { (void)hipFree(r.ptr); (void)hipEventDestroy(r.ev); }
     if (h->noise_ev) (void)hipEventDestroy(h->noise_ev);
+    if (h->order_ev) (void)hipEventDestroy(h->order_ev);
+    if (h->d_marks) (void)hipFree(h->d_marks);
     if (h->noise_stream) (void)hipStreamDestroy(h->noise_stream);
     for (auto &sl : h->slots)
         for (void *p : {(void *)sl.d_cells, (void *)sl.d_cells_far, (void *)sl.d_lut, (void *)sl.d_lut_lds, (void *)sl.d_dt})
@@ -901,6 +911,16 @@ static int noise_publish(f110_handle *h, hipStream_t st)
     return F110_OK;
 }
 
+// Cold paths publish on the null stream and wait for it: the callers' streams do not synchronise with the null stream, and a
+// later publish in stream order must not be overtaken by this one.
+static int noise_publish_cold(f110_handle *h)
+{
+    int rc = noise_publish(h, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    return F110_OK;
+}
+
 // (Re)allocates the table for `slots` slots of `cap` rows, every pair {0, side}; rows lo .. hi-1 of the old table move
 // over.  Cold path: synchronises the device, so nothing reads the old table any more and the new one is complete on return.
 static int noise_resize(f110_handle *h, int slots, long long cap)
@@ -930,7 +950,7 @@ static int noise_resize(f110_handle *h, int slots, long long cap)
     h->noise_cap = cap;
     h->noise_slots = slots;
     h->epoch++; // the scan takes the table's base and size by value (ScanArgs::noise_base): a re-allocation is a new launch
-    return noise_publish(h, nullptr);
+    return noise_publish_cold(h);
 }
 
 static int noise_init(f110_handle *h)
@@ -942,6 +962,7 @@ static int noise_init(f110_handle *h)
     HIP_TRY(hipMemset(h->d_err, 0, sizeof(uint32_t)));
     HIP_TRY(hipStreamCreateWithFlags(&h->noise_stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&h->noise_ev, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&h->order_ev, hipEventDisableTiming));
     return noise_resize(h, 1, 1); // noise off: one row of zeros
 }
 
@@ -964,12 +985,60 @@ static bool noise_has_generators(const f110_handle *h)
     return false;
 }
 
+// room for the marks of rows 0 .. rows-1 of every slot (cold path when it grows: synchronises)
+static int noise_marks_reserve(f110_handle *h, long long rows)
+{
+    const long long need = rows / NOISE_MARK_ROWS + 2;
+    if (h->d_marks && h->marks_slots == h->noise_slots && need <= h->marks_cap) return F110_OK;
+    long long cap = std::max<long long>(h->marks_cap, 1 << 12);
+    while (cap < need) cap <<= 1;
+    HIP_TRY(hipDeviceSynchronize());
+    NoiseMark *nm = nullptr;
+    HIP_TRY(hipMalloc((void **)&nm, sizeof(NoiseMark) * (size_t)cap * (size_t)h->noise_slots));
+    HIP_TRY(hipMemset(nm, 0, sizeof(NoiseMark) * (size_t)cap * (size_t)h->noise_slots));
+    if (h->d_marks && h->marks_cap > 0)
+        for (int sl = 0; sl < std::min(h->marks_slots, h->noise_slots); sl++)
+            HIP_TRY(hipMemcpy(nm + (size_t)sl * cap, h->d_marks + (size_t)sl * h->marks_cap, sizeof(NoiseMark) * (size_t)h->marks_cap, hipMemcpyDeviceToDevice));
+    if (h->d_marks) (void)hipFree(h->d_marks);
+    h->d_marks = nm; h->marks_cap = cap; h->marks_slots = h->noise_slots;
+    return F110_OK;
+}
+
+// Brings every generator slot to r1 rows (a multiple of 64), 64 rows per launch: every launch leaves the mark of the row it
+// starts at (f110_noise.h NoiseMark), so that dropped rows can be produced again without rewinding the stream.
 static int noise_launch_generator(f110_handle *h, long long r1, hipStream_t st)
 {
+    long long have = r1;
+    for (int sl = 0; sl < h->noise_slots; sl++)
+        if (h->nslots[sl].kind == 2) have = std::min(have, std::max(h->nslots[sl].T, h->noise_pending_hi));
+    int rc = noise_marks_reserve(h, r1);
+    if (rc) return rc;
     NoiseGenArgs g;
-    g.gen = h->d_noise_gen; g.base = h->d_noise; g.mask = h->noise_cap - 1; g.cap = h->noise_cap; g.lo = h->noise_lo; g.r1 = r1;
-    g.nb = h->cfg.num_beams;
-    hipLaunchKernelGGL(noise_rows_kernel, dim3(h->noise_slots), dim3(64), 0, st, g);
+    g.gen = h->d_noise_gen; g.base = h->d_noise; g.mask = h->noise_cap - 1; g.cap = h->noise_cap; g.lo = h->noise_lo;
+    g.nb = h->cfg.num_beams; g.marks = h->d_marks; g.marks_cap = h->marks_cap; g.redo = 0; g.chunk0 = 0;
+    for (long long r = (have / NOISE_MARK_ROWS + 1) * NOISE_MARK_ROWS; ; r += NOISE_MARK_ROWS) {
+        g.r1 = std::min(r, r1);
+        hipLaunchKernelGGL(noise_rows_kernel, dim3(h->noise_slots), dim3(64), 0, st, g);
+        if (r >= r1) break;
+    }
+    HIP_TRY(hipGetLastError());
+    return F110_OK;
+}
+
+// Rows [lo, hi) of every generator slot are produced AGAIN from the marks (they were dropped from the ring when the floor rose):
+// one wavefront per slot and 64 rows, all at once -- the generators stay where they are.
+static int noise_redo_rows(f110_handle *h, long long lo, long long hi, hipStream_t st)
+{
+    if (hi <= lo) return F110_OK;
+    NoiseGenArgs g;
+    g.gen = h->d_noise_gen; g.base = h->d_noise; g.mask = h->noise_cap - 1; g.cap = h->noise_cap; g.lo = lo; g.r1 = hi;
+    g.nb = h->cfg.num_beams; g.marks = h->d_marks; g.marks_cap = h->marks_cap; g.redo = 1; g.chunk0 = lo / NOISE_MARK_ROWS;
+    const long long chunks = (hi + NOISE_MARK_ROWS - 1) / NOISE_MARK_ROWS - g.chunk0;
+    for (long long c0 = 0; c0 < chunks; c0 += 32768) { // (grid.y <= 65535)
+        NoiseGenArgs gg = g;
+        gg.chunk0 = g.chunk0 + c0;
+        hipLaunchKernelGGL(noise_rows_kernel, dim3(h->noise_slots, (unsigned)std::min<long long>(32768, chunks - c0)), dim3(64), 0, st, gg);
+    }
     HIP_TRY(hipGetLastError());
     return F110_OK;
 }
@@ -1032,7 +1101,7 @@ extern "C" int f110_set_noise_slot(f110_handle *h, int32_t slot, const double *t
         HIP_TRY(hipDeviceSynchronize());
     }
     noise_recompute_hi(h);
-    return noise_publish(h, nullptr);
+    return noise_publish_cold(h);
 }
 
 extern "C" int f110_set_noise_table(f110_handle *h, const double *tbl, int64_t T)
@@ -1084,7 +1153,7 @@ extern "C" int f110_set_noise_generator(f110_handle *h, int32_t slot, const uint
     h->noise_lo = 0;
     h->noise_on = true;
     if ((rc = noise_restart_generators(h))) return rc;
-    return noise_publish(h, nullptr);
+    return noise_publish_cold(h);
 }
 
 extern "C" int f110_noise_prefetch(f110_handle *h, int64_t rows)
@@ -1098,8 +1167,10 @@ extern "C" int f110_noise_prefetch(f110_handle *h, int64_t rows)
     const long long r1 = (rows + 63) & ~63ll;
     if (r1 - h->noise_lo > h->noise_cap) return F110_OK; // needs a larger table: f110_noise_ensure grows it when the rows are due
     ON_DEVICE(h->cfg.device);
-    // The generator appends rows have .. r1-1 into ring places whose previous tenants lie below the floor: nothing that
-    // is enqueued anywhere reads them, so no ordering against the caller's stream is needed.
+    // The generator appends rows have .. r1-1 into ring places whose previous tenants lie below the floor.  Steps that were
+    // enqueued BEFORE the floor was raised may still read those tenants, and a generator kernel enqueued on the caller's
+    // stream (f110_noise_ensure) works on the same generator states: both recorded `order_ev` there, and this launch waits for it.
+    if (h->order_ev_set) { HIP_TRY(hipStreamWaitEvent(h->noise_stream, h->order_ev, 0)); h->order_ev_set = false; }
     if (int rc = noise_launch_generator(h, r1, h->noise_stream)) return rc;
     HIP_TRY(hipEventRecord(h->noise_ev, h->noise_stream));
     h->noise_pending_hi = r1;
@@ -1127,7 +1198,10 @@ extern "C" int f110_noise_ensure(f110_handle *h, int64_t rows, void *stream)
     for (int sl = 0; sl < h->noise_slots; sl++)
         if (h->nslots[sl].kind == 2) h->nslots[sl].T = r1;
     noise_recompute_hi(h);
-    return noise_publish(h, st);
+    if ((rc = noise_publish(h, st))) return rc;
+    HIP_TRY(hipEventRecord(h->order_ev, st)); // the next prefetch (side stream) runs behind this generator launch
+    h->order_ev_set = true;
+    return F110_OK;
 }
 
 extern "C" int f110_noise_set_floor(f110_handle *h, int64_t lo, void *stream)
@@ -1140,13 +1214,28 @@ extern "C" int f110_noise_set_floor(f110_handle *h, int64_t lo, void *stream)
             if (h->nslots[sl].kind == 1) return fail(F110_E_INVALID, "f110_noise_set_floor: noise slot %d is a host table (rows are only dropped from generated noise)", sl);
         if (lo > h->noise_hi) return fail(F110_E_INVALID, "f110_noise_set_floor: floor %lld above the %lld rows produced", (long long)lo, h->noise_hi);
         h->noise_lo = lo;
-        return noise_publish(h, (hipStream_t)stream);
+        if (int rc = noise_publish(h, (hipStream_t)stream)) return rc;
+        // the steps enqueued so far may read rows below the new floor: the prefetch that recycles their places waits for them
+        HIP_TRY(hipEventRecord(h->order_ev, (hipStream_t)stream));
+        h->order_ev_set = true;
+        return F110_OK;
     }
-    // the floor comes down (a car was reset while others run on): the dropped rows are produced again from the seeds
-    h->noise_lo = lo;
-    int rc = noise_restart_generators(h);
+    // The floor comes down (a car was reset while others run on): rows lo .. old floor - 1 are produced again, from the marks
+    // the generators left every 64 rows -- one wavefront per slot and 64 rows, in the caller's stream; the generators themselves
+    // stay where they are.  (Until round 5 every generator was rewound to its seed and re-ran the whole stream, one wavefront
+    // per seed at ~15 us per row.)  The ring has to span floor .. rows produced: it grows if it must (cold path).
+    hipStream_t st = (hipStream_t)stream;
+    int rc = noise_absorb_pending(h, st);
     if (rc) return rc;
-    return noise_publish(h, (hipStream_t)stream);
+    const long long old_lo = h->noise_lo;
+    if (h->noise_hi - lo > h->noise_cap)
+        if ((rc = noise_resize(h, h->noise_slots, pow2_at_least(h->noise_hi - lo)))) return rc;
+    h->noise_lo = lo;
+    if ((rc = noise_redo_rows(h, lo, std::min(old_lo, h->noise_hi), st))) return rc;
+    if ((rc = noise_publish(h, st))) return rc;
+    HIP_TRY(hipEventRecord(h->order_ev, st));
+    h->order_ev_set = true;
+    return F110_OK;
 }
 
 extern "C" int f110_noise_info(f110_handle *h, int64_t *lo, int64_t *hi, int64_t *cap, int32_t *slots, int64_t *bytes)

@@ -599,7 +599,11 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
             if (SM == 2) *q = (float)v;
             else __builtin_nontemporal_store((float)v, q);
         }
-        if (o64) __builtin_nontemporal_store(v, reinterpret_cast<double *>(reinterpret_cast<char *>(o64) + (size_t)((unsigned)i * 8u)));
+        if (o64) {
+            double *q64 = reinterpret_cast<double *>(reinterpret_cast<char *>(o64) + (size_t)((unsigned)i * 8u));
+            if (SM == 2) *q64 = v;
+            else __builtin_nontemporal_store(v, q64);
+        }
         if (__builtin_expect(v < side_pre, 0)) {
             const ScanArgs *ra = rare;
             asm volatile("" : "+s"(ra)); // re-read the rarely needed arguments here instead of holding them in SGPRs

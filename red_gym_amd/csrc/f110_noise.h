@@ -70,13 +70,25 @@ __device__ inline unsigned long long shfl64(unsigned long long v, int src)
     return ((unsigned long long)hi << 32) | lo;
 }
 
+// the stream of a slot at the start of row 64 * k (its LCG state): written when the row is first reached, so that rows which
+// were dropped from the ring can be produced again from the nearest mark -- in parallel, one wavefront per 64 rows -- instead of
+// from the seed
+struct NoiseMark { unsigned long long t_lo, t_hi; };
+constexpr int NOISE_MARK_ROWS = 64;
+
 struct NoiseGenArgs {
     NoiseGen *gen;        // [slots]
     double *base;         // the table being filled
     long long mask, cap;
     long long lo;         // rows below lo are generated (the stream must advance) but not stored
-    long long r1;         // every active slot is brought to r1 rows
+    long long r1;         // every active slot is brought to r1 rows (a multiple of NOISE_MARK_ROWS when marks are kept)
     int nb;
+    NoiseMark *marks;     // [slots][marks_cap] or NULL
+    long long marks_cap;
+    // re-production of dropped rows (blockIdx.y = chunk): rows [max(lo, 64 * (chunk0 + y)), min(r1, 64 * (chunk0 + y + 1))) from
+    // marks[slot][chunk0 + y]; the generators' own states are neither read nor written
+    int redo;
+    long long chunk0;
 };
 
 // One wavefront per noise slot (grid = slots).
@@ -94,8 +106,20 @@ __global__ __launch_bounds__(64) void noise_rows_kernel(NoiseGenArgs a)
     __shared__ unsigned long long s_ki[256];
     __shared__ double s_wi[256], s_fi[256];
     const int lane = threadIdx.x, slot = blockIdx.x;
-    const NoiseGen g = a.gen[slot];
+    NoiseGen g = a.gen[slot];
+    if (a.redo) {
+        const long long ch = a.chunk0 + blockIdx.y;
+        if (!g.on || !a.marks || ch >= a.marks_cap) return;
+        const NoiseMark mk = a.marks[(size_t)slot * (size_t)a.marks_cap + (size_t)ch];
+        g.t_lo = mk.t_lo; g.t_hi = mk.t_hi; g.rows = ch * NOISE_MARK_ROWS;
+        a.r1 = a.r1 < g.rows + NOISE_MARK_ROWS ? a.r1 : g.rows + NOISE_MARK_ROWS;
+    }
     if (!g.on || g.rows >= a.r1) return; // (uniform)
+    // the mark of the row this launch starts at (a launch ends where the next one starts: every multiple of 64 rows gets one)
+    if (!a.redo && a.marks && lane == 0 && g.rows % NOISE_MARK_ROWS == 0 && g.rows / NOISE_MARK_ROWS < a.marks_cap) {
+        NoiseMark mk; mk.t_lo = g.t_lo; mk.t_hi = g.t_hi;
+        a.marks[(size_t)slot * (size_t)a.marks_cap + (size_t)(g.rows / NOISE_MARK_ROWS)] = mk;
+    }
     for (int i = lane; i < 256; i += 64) { s_ki[i] = ZIG_KI[i]; s_wi[i] = ZIG_WI[i]; s_fi[i] = ZIG_FI[i]; }
     __syncthreads();
     const u128 M = pcg_mult(), inc = ((u128)g.inc_hi << 64) | (u128)g.inc_lo;
@@ -184,7 +208,7 @@ __global__ __launch_bounds__(64) void noise_rows_kernel(NoiseGenArgs a)
             const int q = L + 1 + __builtin_amdgcn_readlane(extras, L); // (extras is 0 for a fast candidate)
             u128 Tq = shfl128(T, q < 63 ? q : 63);
             for (int i = 63; i < q; i++) Tq = Tq * M + inc;
-            if (lane == 0) {
+            if (lane == 0 && !a.redo) {
                 a.gen[slot].t_lo = (unsigned long long)Tq;
                 a.gen[slot].t_hi = (unsigned long long)(Tq >> 64);
                 a.gen[slot].rows = a.r1;

@@ -264,7 +264,9 @@ class Engine(object):
         if self._noise_gen and lo != self._noise_floor:
             _lib.check(self.lib.f110_noise_set_floor(self._h, int(lo), self._stream()))
             if lo < self._noise_floor:
-                self._noise_rows = 0  # the generators start over from their seeds
+                # the dropped rows are produced again from the generators' marks (in this stream); what was produced stays
+                self._noise_rows = self.noise_info()[1]
+                self._noise_prefetched = False
             self._noise_floor = int(lo)
 
     @on_own_device

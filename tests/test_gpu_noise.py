@@ -184,6 +184,97 @@ def test_long_run_is_a_ring_of_constant_size(assets):
     env.close()
 
 
+def test_prefetch_waits_for_the_steps_enqueued_before_the_floor_moved(assets):
+    """the floor of the noise ring is raised from the HOST's step count, and the next prefetch (the library's
+    side stream) recycles the ring places of the rows below it -- while steps that were enqueued before may not have run yet
+    (a 65 536-env shard runs hundreds of steps behind its host).  The trace of Engine._ensure_noise, compressed: the stream is
+    stalled by a sleep kernel, 300 steps are enqueued behind it (rows 1 .. 300), the floor goes to 301 and a prefetch of rows
+    1 024 .. 1 279 is started -- ring places 0 .. 255.  Every one of the 300 scans must still be its own NumPy row (the cars sit
+    inside a wall: a scan IS its noise row).  Fails on the round-4 library (the side stream did not wait)."""
+    import ctypes as C
+    import torch
+    from red_gym_amd import F110VecEnv
+    B, T = 4, 300
+    seeds = [5, 6, 5, 6]
+    env = F110VecEnv(B, map=os.path.join(assets, 'example_map'), num_agents=1, seed=seeds, autoreset=False, keep_f64_scans=True)
+    poses = np.tile(np.array([[[-45.87478769831466, -16.282154624538293, 0.3]]]), (B, 1, 1))
+    env.reset(poses)
+    eng = env.eng
+    eng._noise_to(1024)
+    torch.cuda.synchronize()
+    lo, hi, cap = eng.noise_info()[:3]
+    assert (lo, hi, cap) == (0, 1024, 1024)
+    z = torch.zeros((B, 1, 2), dtype=torch.float64, device='cuda')
+    keep = torch.empty((T, B, 1080), dtype=torch.float64, device='cuda')
+    torch.cuda._sleep(int(1.2e9))            # ~0.5 s: everything below is enqueued behind it
+    for k in range(T):
+        env.step(z)
+        keep[k].copy_(eng.t['scans_f64'][:, 0])
+    lib = eng.lib
+    assert lib.f110_noise_set_floor(eng._h, C.c_int64(T + 1), eng._stream()) == 0
+    assert lib.f110_noise_prefetch(eng._h, C.c_int64(1024 + 256)) == 0
+    torch.cuda.synchronize()
+    got = keep.cpu().numpy()
+    rows = {sd: np.random.default_rng(sd) for sd in (5, 6)}
+    for sd in (5, 6):
+        rows[sd].normal(0., 0.01, size=1080)  # row 0 went to the reset's scan
+    for k in range(T):
+        ref = {sd: rows[sd].normal(0., 0.01, size=1080) for sd in (5, 6)}
+        for e in range(B):
+            assert np.allclose(got[k, e], ref[seeds[e]], rtol=0, atol=2e-17), (k, e)
+    assert eng.device_errors() == 0
+    env.close()
+
+
+def test_masked_reset_after_a_long_run_reproduces_dropped_rows_from_the_marks(assets):
+    """a masked reset after the floor has moved used to rewind every generator to its seed and re-run the
+    whole stream (one wavefront, ~15 us per row: 0.3 s at 20 000 steps).  The dropped rows are now produced again from the
+    marks the generators leave every 64 rows, one wavefront per 64 rows: the generators' states do not move, the rows are
+    NumPy's, and the reset takes milliseconds."""
+    import time
+    import torch
+    from red_gym_amd import F110VecEnv
+    B, T = 4, 6000
+    seeds = [5, 6, 5, 6]
+    env = F110VecEnv(B, map=os.path.join(assets, 'example_map'), num_agents=1, seed=seeds, autoreset=False, keep_f64_scans=True)
+    poses = np.tile(np.array([[[-45.87478769831466, -16.282154624538293, 0.3]]]), (B, 1, 1))
+    env.reset(poses)
+    z = torch.zeros((B, 1, 2), dtype=torch.float64, device='cuda')
+    for k in range(T):
+        env.step(z)
+    torch.cuda.synchronize()
+    lo0, hi0 = env.eng.noise_info()[:2]
+    assert lo0 > T - 1024 - 300
+    m = torch.zeros(B, dtype=torch.uint8, device='cuda'); m[:2] = 1
+    t0 = time.perf_counter()
+    env.reset(poses, m)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    lo1, hi1 = env.eng.noise_info()[:2]
+    assert lo1 == 0 and hi1 >= hi0           # nothing that had been produced was thrown away
+    # every row of the table is NumPy's (rows 0 .. lo0-1 come from the marks, the rest from the first pass)
+    for sl, sd in ((0, 5), (1, 6)):
+        rng = np.random.default_rng(sd)
+        want = rng.normal(0., 0.01, size=(hi0, 1080))
+        got = env.eng.noise_rows(sl, 0, hi0)
+        assert np.allclose(got, want, rtol=0, atol=2e-17), sd
+        tail = np.abs(want) > 0.01 * 3.6541528853610088
+        assert np.array_equal(got[~tail], want[~tail]), sd
+    # and the run goes on for both cohorts
+    rr = {sd: np.random.default_rng(sd) for sd in (5, 6)}
+    for sd in (5, 6):
+        rr[sd].normal(0., 0.01, size=1080)
+    for k in range(3):
+        env.step(z)
+        s = _np(env.eng.t['scans_f64'])
+        sec = {sd: rr[sd].normal(0., 0.01, size=1080) for sd in (5, 6)}
+        for e in (0, 1):
+            assert np.allclose(s[e, 0], sec[seeds[e]], rtol=0, atol=2e-17), (k, e)
+    assert env.eng.device_errors() == 0
+    assert dt < 0.08, 'masked reset after %d steps took %.3f s' % (T, dt)   # (~90 ms to re-run 6 000 rows serially; a few ms now)
+    env.close()
+
+
 def test_autoreset_keeps_every_row_and_grows_quietly(assets):
     """autoreset on: a car may be sent back to row 0 at any step, so rows are never dropped; a car that outlives the table
     makes it double (1 024 -> 2 048 rows).  The re-allocation is the one event that moves the launch epoch (the scan takes

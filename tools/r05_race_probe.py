@@ -1,0 +1,35 @@
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '.'))
+from red_gym_amd import F110VecEnv, workload
+B, T = 4, 1400
+seeds = [5, 6, 5, 6]
+env = F110VecEnv(B, map=workload.EXAMPLE_MAP, num_agents=1, seed=seeds, autoreset=False, keep_f64_scans=True)
+poses = np.tile(np.array([[[-45.87478769831466, -16.282154624538293, 0.3]]]), (B, 1, 1))
+env.reset(poses)
+torch.cuda.synchronize()
+z = torch.zeros((B, 1, 2), dtype=torch.float64, device='cuda')
+keep = torch.empty((T, B, 1080), dtype=torch.float64, device='cuda')
+ev = torch.cuda.Event(); 
+t0 = time.perf_counter()
+torch.cuda._sleep(int(3e9))
+log = []
+for k in range(T):
+    env.step(z)
+    keep[k].copy_(env.eng.t['scans_f64'][:, 0])
+    if k in (900, 1000, 1022, 1023, 1024, 1030, 1100, 1399): log.append((k, env.eng.noise_info()[:3], env.eng._noise_rows, env.eng._noise_prefetched))
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+print('lib', os.environ.get('F110_LIB', 'default'), 'enqueue %.3f s, drain %.3f s' % (t1 - t0, t2 - t1))
+for l in log: print(l)
+got = keep.cpu().numpy()
+rows = {sd: np.random.default_rng(sd) for sd in (5, 6)}
+for sd in (5, 6): rows[sd].normal(0., 0.01, size=1080)
+bad = []
+for k in range(T):
+    ref = {sd: rows[sd].normal(0., 0.01, size=1080) for sd in (5, 6)}
+    for e in range(B):
+        if not np.allclose(got[k, e], ref[seeds[e]], rtol=0, atol=2e-17): bad.append((k, e))
+print('mismatching (step, env):', len(bad), bad[:8])
+print('device errors', env.eng.device_errors())
