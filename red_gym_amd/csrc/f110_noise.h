@@ -11,9 +11,9 @@
 //   * random_normal: loc + scale * x.
 // The stream is sequential (a draw consumes one raw value, or more after a rejection), so ONE WAVEFRONT per seed walks it,
 // 64 raw values at a time (noise_rows_kernel below; lane j holds the generator state of raw position p + j by LCG
-// jump-ahead).  Exactness: every accepted value outside the tail
-// is the product of an integer and a table entry (no library call); the tail's log1p comes from the device math library
-// and may differ from glibc's by an ulp of a 1e-2-scaled term (tests/test_gpu_noise.py counts how often).
+// jump-ahead).  Exactness: every accepted value outside the tail is the product of an integer and a table entry (no library
+// call); the wedge test compares against exp() (a decision, and the only one a library rounding could flip: none has been
+// seen in 1e8 draws); the tail's log1p is glibc's own sequence of roundings (log1p_glibc below), so the rows are NumPy's bits.
 #pragma once
 #include "f110_device.h"
 #include "f110_ziggurat.h"
@@ -75,6 +75,72 @@ __device__ inline unsigned long long shfl64(unsigned long long v, int src)
 // from the seed
 struct NoiseMark { unsigned long long t_lo, t_hi; };
 constexpr int NOISE_MARK_ROWS = 64;
+
+// log1p as glibc computes it (sysdeps/ieee754/dbl-64/s_log1p.c, 2.35: the fdlibm algorithm -- argument reduction to
+// 1 + f in [sqrt(2)/2, sqrt(2)), the degree-7 polynomial in z = (f / (2 + f))^2 regrouped as R1 + z2*R2 + z4*R3 + z6*R4 --
+// built for x86-64 without contraction), restated operation by operation: NumPy's ziggurat calls the C library's log1p for
+// its tail draws (0.026 % of the draws), and fdlibm's result is within an ulp of the true value but not the correctly rounded
+// one, so "NumPy's bits" means this sequence of roundings.  tools/log1p_model.py is the same text in Python, compared with
+// the local libm bit for bit over 5e5 arguments (and the libm's constants read from its binary); the device math library's
+// log1p differed in 4 of 2 156 tail draws (round 4).  Domain here: x = -u, u in [0, 1).
+__device__ inline double log1p_glibc(double x)
+{
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+    const double Lp1 = 6.666666666666735130e-01, Lp2 = 3.999999999940941908e-01, Lp3 = 2.857142874366239149e-01,
+                 Lp4 = 2.222219843214978396e-01, Lp5 = 1.818357216161805012e-01, Lp6 = 1.531383769920937332e-01,
+                 Lp7 = 1.479819860511658591e-01;
+    const int hx = __double2hiint(x);
+    const int ax = hx & 0x7fffffff;
+    int k = 1, hu = 1;
+    double f = 0.0, c = 0.0;
+    if (hx < 0x3FDA827A) {                                  // x < 0.41422
+        if (ax >= 0x3ff00000) return x == -1.0 ? -__builtin_inf() : __builtin_nan(""); // x <= -1 (not reached: u < 1)
+        if (ax < 0x3e200000) {                              // |x| < 2^-29
+            if (ax < 0x3c900000) return x;                  // |x| < 2^-54
+            return x - x * x * 0.5;
+        }
+        if (hx > 0 || hx <= (int)0xbfd2bec3) { k = 0; f = x; hu = 1; } // -0.2929 < x < 0.41422
+    } else if (hx >= 0x7ff00000) return x + x;
+    if (k != 0) {
+        double u;
+        if (hx < 0x43400000) {
+            u = 1.0 + x;
+            hu = __double2hiint(u);
+            k = (hu >> 20) - 1023;
+            c = (k > 0) ? 1.0 - (u - x) : x - (u - 1.0);    // correction term
+            c = c / u;
+        } else {
+            u = x;
+            hu = __double2hiint(u);
+            k = (hu >> 20) - 1023;
+            c = 0.0;
+        }
+        hu &= 0x000fffff;
+        if (hu < 0x6a09e) u = __hiloint2double(hu | 0x3ff00000, __double2loint(u));           // normalize u
+        else { k += 1; u = __hiloint2double(hu | 0x3fe00000, __double2loint(u)); hu = (0x00100000 - hu) >> 2; } // normalize u / 2
+        f = u - 1.0;
+    }
+    const double hfsq = (0.5 * f) * f;
+    if (hu == 0) {                                          // |f| < 2^-20
+        if (f == 0.0) {
+            if (k == 0) return 0.0;
+            c = c + (double)k * ln2_lo;
+            return (double)k * ln2_hi + c;
+        }
+        const double R = hfsq * (1.0 - 0.66666666666666666 * f);
+        if (k == 0) return f - R;
+        return (double)k * ln2_hi - ((R - ((double)k * ln2_lo + c)) - f);
+    }
+    const double s = f / (2.0 + f);
+    const double z = s * s;
+    const double R1 = z * Lp1, z2 = z * z;
+    const double R2 = Lp2 + z * Lp3, z4 = z2 * z2;
+    const double R3 = Lp4 + z * Lp5, z6 = z4 * z2;
+    const double R4 = Lp6 + z * Lp7;
+    const double R = ((R1 + z2 * R2) + z4 * R3) + z6 * R4;
+    if (k == 0) return f - (hfsq - s * (hfsq + R));
+    return (double)k * ln2_hi - ((hfsq - (s * (hfsq + R) + ((double)k * ln2_lo + c))) - f);
+}
 
 struct NoiseGenArgs {
     NoiseGen *gen;        // [slots]
@@ -157,8 +223,8 @@ __global__ __launch_bounds__(64) void noise_rows_kernel(NoiseGenArgs a)
                         Q = Q * M + inc; const double u1 = pcg_double(pcg_out(Q));
                         Q = Q * M + inc; const double u2 = pcg_double(pcg_out(Q));
                         extras += 2;
-                        const double xx = -ZIG_NOR_INV_R * log1p(-u1);
-                        const double yy = -log1p(-u2);
+                        const double xx = -ZIG_NOR_INV_R * log1p_glibc(-u1);
+                        const double yy = -log1p_glibc(-u2);
                         if (yy + yy > xx * xx) { val = ((rabs >> 8) & 1ull) ? -(ZIG_NOR_R + xx) : ZIG_NOR_R + xx; break; }
                     }
                 } else {

@@ -32,26 +32,27 @@ def _engine(assets, **kw):
 
 
 def test_device_rows_are_numpys_rows(assets, golden):
-    """Rows 0..1299 of six seeds `==` np.random.default_rng(seed).normal(0, 0.01, 1080) bit for bit outside the tail draws
-    and within one ulp of the tail value (|x| about 3.7..5, so 9e-16 x 0.01) there (the tail of the ziggurat calls log1p: device math library against glibc).
+    """Rows 0..1299 of eight seeds `==` np.random.default_rng(seed).normal(0, 0.01, 1080) BIT FOR BIT, every draw: 11.2 M draws, of
+    which ~2 900 come from the ziggurat's tail branch (|x| > 3.654: NumPy calls the C library's log1p there; the device restates
+    glibc's log1p operation by operation, csrc/f110_noise.h log1p_glibc -- round 4 used the device math library and 4 of 2 156
+    tail draws differed by an ulp).  The comparison is against the NumPy of the machine the test runs on (glibc 2.35 in this image).
     1 300 rows cross the first growth of the table (1 024 -> 2 048 rows per slot).  Seed 12345's first rows are also
     the reference-generated golden g2."""
-    seeds = [12345, 0, 1, 7, 2 ** 31, 987654321987]
+    seeds = [12345, 0, 1, 7, 2 ** 31, 987654321987, 42, 2 ** 63 + 5]
     e = _engine(assets, num_envs=len(seeds), seed=seeds, noise_steps=1300)
     g2 = golden('g2_noise.npz')['seed12345']
-    n_tail = n_diff = 0
+    n_tail = n_draws = 0
     for k, sd in enumerate(seeds):
         got = e.noise_rows(k, 0, 1300)
         rng = np.random.default_rng(sd)
         ref = np.stack([rng.normal(0., 0.01, size=1080) for _ in range(1300)])
         tail = np.abs(ref) > 0.01 * 3.6541528853610088          # |x| > ziggurat_nor_r: produced by the log1p branch
-        assert np.array_equal(got[~tail], ref[~tail]), sd
-        assert np.allclose(got[tail], ref[tail], rtol=0, atol=2e-17), sd
-        n_tail += int(tail.sum()); n_diff += int((got != ref).sum())
+        assert np.array_equal(got, ref), (sd, int((got != ref).sum()), int(tail.sum()))
+        n_tail += int(tail.sum()); n_draws += ref.size
         if sd == 12345:
-            assert np.array_equal(got[:g2.shape[0]][~tail[:g2.shape[0]]], g2[~tail[:g2.shape[0]]])
-    assert n_tail > 500                                          # 0.026 % of 8.4 M draws
-    print('tail draws: %d, of which not bit-identical to glibc: %d' % (n_tail, n_diff))
+            assert np.array_equal(got[:g2.shape[0]], g2)
+    assert n_draws >= 10 ** 7 and n_tail >= 2000, (n_draws, n_tail)   # 0.026 % of the draws
+    print('draws: %d, tail draws: %d, all bit-identical to NumPy' % (n_draws, n_tail))
     assert e.device_errors() == 0
     e.close()
 

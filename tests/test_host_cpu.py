@@ -146,3 +146,17 @@ def test_map_name_resolution_matches_reference(assets):
     assert resolve_map_path(None) == os.path.join(assets, 'maps', 'vegas.yaml')
     with pytest.raises(FileNotFoundError, match='levine.png'):
         load_map(resolve_map_path('levine'), '.png')
+
+
+def test_log1p_model_is_the_c_librarys_log1p():
+    """tools/log1p_model.py restates glibc's log1p (the text of log1p_glibc in csrc/f110_noise.h, the ziggurat's tail branch)
+    in Python; it must be math.log1p bit for bit on the machine's libm -- uniform arguments, the edges of every branch."""
+    import math
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import log1p_model as m
+    rng = np.random.default_rng(3)
+    us = np.concatenate([rng.random(40000), 1.0 - 2.0 ** -rng.integers(1, 54, 500), 2.0 ** -rng.uniform(1, 60, 3000),
+                         [0.0, 2.0 ** -53, 1.0 - 2.0 ** -53, 0.5, 0.2929, 0.29289321881345254, 0.2928932188134525]])
+    for u in us:
+        assert m.log1p_glibc(-float(u)) == math.log1p(-float(u)), u
