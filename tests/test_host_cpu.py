@@ -152,8 +152,7 @@ def test_log1p_model_is_the_c_librarys_log1p():
     """tools/log1p_model.py restates glibc's log1p (the text of log1p_glibc in csrc/f110_noise.h, the ziggurat's tail branch)
     in Python; it must be math.log1p bit for bit on the machine's libm -- uniform arguments, the edges of every branch."""
     import math
-    import sys
-    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
     import log1p_model as m
     rng = np.random.default_rng(3)
     us = np.concatenate([rng.random(40000), 1.0 - 2.0 ** -rng.integers(1, 54, 500), 2.0 ** -rng.uniform(1, 60, 3000),
