@@ -52,7 +52,7 @@ def cpu_baseline(num_agents, budget_s=12.0):
     cores = usable_cores()
     sc = oracle.Scanner(1080, 2 * np.pi)
     sc.set_map(workload.EXAMPLE_MAP + '.yaml', '.png')
-    B = 64 * cores
+    B = 1024   # the same sample whatever the box (round 4 scaled it with the core count)
     noise = oracle.noise_table(12345, 4096)
     batch = oracle.Batch(sc, B, num_agents, workload.spawn_poses(B, num_agents), noise=noise)
     acts = workload.action_pool(8, B, num_agents)
@@ -116,33 +116,62 @@ class Ranks(object):
                 with socket.socket() as s:
                     s.bind(('127.0.0.1', 0))
                     os.environ['MASTER_PORT'] = str(s.getsockname()[1])
+            self._init_group(backend, device)
+
+    GROUP_TIMEOUT_S = 180   # rendezvous, every collective of the bench and the backend vote: a dead rank ends the run
+
+    def _init_group(self, backend, device):
+        """One TCPStore (rank 0 hosts it at MASTER_ADDR:MASTER_PORT) carries everything: the process group's rendezvous,
+        the ranks' VOTE on the backend, and -- if RCCL cannot start on ANY rank -- the gloo group that replaces it.  Every
+        rank tries the asked-for backend (a probe all_reduce makes RCCL create its communicators here, where a failure can
+        still be handled), publishes ok / failed under its own key and reads everybody's: the ranks fall back TOGETHER or
+        not at all (round 4 let each rank decide for itself: a rank whose probe had succeeded stayed in the RCCL group and
+        the others waited for it in a gloo barrier for ever).  The ranks only meet for barriers and two tiny gathers
+        around the timed region -- no collective on the step path -- so the measurement is the same over gloo; the JSON
+        line says which backend synchronised the ranks.  Every wait has a timeout."""
+        import datetime
+        dist = self.dist
+        tmo = datetime.timedelta(seconds=self.GROUP_TIMEOUT_S)
+        store = dist.TCPStore(os.environ['MASTER_ADDR'], int(os.environ['MASTER_PORT']), self.world, is_master=(self.rank == 0),
+                              timeout=tmo, wait_for_workers=False)
+        self._store = store
+        fail_ranks = [int(r) for r in os.environ.get('F110_BENCH_TEST_PRIMARY_FAILS', '').split(',') if r.strip()]  # tests only
+        err = None
+        try:
+            with _stdout_to_stderr():
+                kw = {'device_id': device} if backend == 'nccl' else {}
+                dist.init_process_group(backend, store=dist.PrefixStore('primary', store), rank=self.rank, world_size=self.world,
+                                        timeout=tmo, **kw)
+            if self.rank in fail_ranks:
+                raise RuntimeError('injected failure of the primary backend (F110_BENCH_TEST_PRIMARY_FAILS)')
             if backend == 'nccl':
-                try:
-                    dist.init_process_group('nccl', rank=self.rank, world_size=self.world, device_id=device)
-                    import torch
-                    probe = torch.zeros(1, device=device)          # communicators are created lazily: make RCCL prove itself
-                    dist.all_reduce(probe)                          # here, where a failure can still be handled
-                    torch.cuda.synchronize(device)
-                except Exception as e:  # noqa: BLE001 -- whatever RCCL raises on this node
-                    # The ranks only meet for barriers and two tiny gathers around the timed region (no collective on the
-                    # step path), so a node where RCCL cannot start still gives the same measurement over gloo; the JSON
-                    # line says which one synchronised the ranks.
-                    sys.stderr.write('bench.py: rank %d: RCCL failed to start (%s: %s); synchronising the ranks over gloo\n'
-                                     % (self.rank, type(e).__name__, e))
-                    try:
-                        dist.destroy_process_group()
-                    except Exception:  # noqa: BLE001
-                        pass
-                    self.backend = 'gloo'
-                    port = int(os.environ['MASTER_PORT']) + 1      # a fresh store: the failed group may have left keys behind
-                    with _stdout_to_stderr():
-                        dist.init_process_group('gloo', init_method='tcp://%s:%d' % (os.environ['MASTER_ADDR'], port),
-                                                rank=self.rank, world_size=self.world)
-                        dist.barrier()
-            else:
-                with _stdout_to_stderr():
-                    dist.init_process_group(backend, rank=self.rank, world_size=self.world)
-                    dist.barrier()
+                import torch
+                probe = torch.zeros(1, device=device)
+                dist.all_reduce(probe)
+                torch.cuda.synchronize(device)
+        except Exception as e:  # noqa: BLE001 -- whatever the backend raises on this node
+            err = e
+            sys.stderr.write('bench.py: rank %d: backend %s failed to start (%s: %s)\n' % (self.rank, backend, type(e).__name__, e))
+        store.set('vote/%d' % self.rank, b'0' if err else b'1')
+        store.wait(['vote/%d' % r for r in range(self.world)], tmo)
+        all_ok = all(store.get('vote/%d' % r) == b'1' for r in range(self.world))
+        if all_ok:
+            with _stdout_to_stderr():
+                dist.barrier(device_ids=[device.index]) if backend == 'nccl' else dist.barrier()
+            return
+        if backend == 'gloo' and not fail_ranks:
+            raise RuntimeError('bench.py: the gloo process group could not be built: %r' % (err,))
+        if self.rank == 0:
+            sys.stderr.write('bench.py: backend %s did not start on every rank; all %d ranks synchronise over gloo\n' % (backend, self.world))
+        try:
+            if dist.is_initialized():
+                dist.destroy_process_group()
+        except Exception:  # noqa: BLE001
+            pass
+        self.backend = 'gloo'
+        with _stdout_to_stderr():
+            dist.init_process_group('gloo', store=dist.PrefixStore('fallback', store), rank=self.rank, world_size=self.world, timeout=tmo)
+            dist.barrier()
 
     def _comm_device(self):
         return self.device if self.backend == 'nccl' else 'cpu'
@@ -314,6 +343,9 @@ def main(argv=None):
     ap.add_argument('--sustained', type=int, default=200,
                     help='after the timed region, time this many further steps (clocks up, cars scattered) and report '
                          'them as `sustained` beside `value` (0 = skip); never part of `value`')
+    ap.add_argument('--steady-state', type=int, default=200,
+                    help='after `sustained`, stagger the envs over 1 024 noise rows (the regime of a long-running batch) and time '
+                         'this many steps; reported as `steady_state` beside `value` (0 = skip); never part of `value`')
     ap.add_argument('--repeats', type=int, default=1,
                     help='R > 1: after the protocol region (which alone gives `value`), R - 1 further timed regions of K steps '
                          'each; the median of all R is reported beside it as `median_of_repeats` (SURVEY 8d: median of 5)')
@@ -430,6 +462,28 @@ def main(argv=None):
                      'note': 'the %d steps right after the timed region (GPU clocks up, cars scattered by random '
                              'driving); not part of `value`' % args.sustained}
 
+    steady = None
+    if args.steady_state > 0 and env.eng._noise_on:
+        # `value`, `sustained` and the regions above run right after a reset: every car stands on the SAME noise row, which
+        # the whole chip then reads from the L1.  A batch that has been running for a while (autoreset at different
+        # times) has every env on its own row, and the rows stream from L2 / HBM.  That regime is set up directly: the
+        # envs' row counters are staggered over 1 024 rows (a device-side write; the host's upper bound follows), a few
+        # steps settle it, and a further region is timed.
+        ns = env.eng.t['noise_step']
+        stagger = torch.randint(1, 1025, (B, 1), device=dev, dtype=ns.dtype, generator=torch.Generator(device=dev).manual_seed(5 + rank))
+        ns.copy_(ns + stagger)
+        env.eng.host_steps_bound += 1024
+        for k in range(20):
+            step_fn(k)
+        env.eng.profile_begin(1, every=NEVER)
+        el3 = timed_steps(ranks, lambda k: step_fn(K + k), args.steady_state)
+        env.eng.profile_end()
+        steady = {'value': world * B * args.steady_state / el3, 'unit': 'env-steps/s', 'steps': args.steady_state,
+                  'ms_per_step': el3 / args.steady_state * 1e3,
+                  'note': 'every env on its own noise row (row counters staggered over 1 024 rows, as in a batch whose envs were '
+                          'reset at different times): the rows stream from L2 / HBM instead of one row from the L1; `value` is '
+                          'the protocol region right after a common reset, the friendliest regime for the noise gather'}
+
     out = None
     if rank == 0:
         value = world * B * K / elapsed
@@ -466,9 +520,9 @@ def main(argv=None):
                     'model': 'SURVEY 8(d) algorithmic bytes: lookups*4 + cars*(1080*4 + 72), not HBM traffic',
                     'traffic_gbs': (traffic / avg_s / 1e9) if traffic else None,
                     'traffic_frac': (traffic / avg_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                    'limiter': 'VALU issue (~85 % of SIMD slots busy) and the L1 address / tag path (381 M accesses per '
-                               '65 536-car launch, every memory instruction takes its turn there); not HBM; see DESIGN.md 5 '
-                               'and profiles/r04_scan_stores.txt'}
+                    'limiter': 'the L1 address / tag path (368 M accesses + 90 M misses per 65 536-car launch: every look-up of a '
+                               'marching ray is one) with VALU issue at ~72 % of the SIMD cycles and the latency of the refill '
+                               'phases; not HBM; see DESIGN.md 5 and profiles/r05_scan_budget.txt'}
         out = {'metric': 'env steps/sec (all envs), 1080-beam lidar', 'value': value, 'unit': 'env-steps/s',
                'n_gpus': world, 'steps': K, 'warmup': W, 'spinup_steps': args.spinup, 'ms_per_step': elapsed / K * 1e3,
                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
@@ -482,7 +536,7 @@ def main(argv=None):
                           'sharding': 'independent env shards, no collective on the step path'},
                'per_rank_ms': [t / K * 1e3 for t in per_rank], 'devices': names,
                'rank_sync': ('rccl' if ranks.backend == 'nccl' else ranks.backend) if ranks.grouped else 'none (one rank)',
-               'roofline': roof, 'sustained': sustained}
+               'roofline': roof, 'sustained': sustained, 'steady_state': steady}
         if repeats:
             out['median_of_repeats'] = repeats
         if world == 1 and not args.no_cpu_baseline:

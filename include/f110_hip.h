@@ -48,6 +48,8 @@ extern "C" {
 #define F110_E_INDEX (-4)    /* agent index out of range (base_classes.py:525-527) */
 #define F110_E_UNBOUND (-5)  /* step/reset before f110_bind */
 
+#define F110_MAX_CARS (1 << 26) /* num_envs * num_agents of one handle (32-bit wave / lane indices; offsets into the
+                                  * per-car tensors are 64-bit): 67 M cars, 290 GB of fp32 scans alone at 1080 beams */
 #define F110_MAX_AGENTS 32
 #define F110_MAX_MAPS 64  /* map slots of one handle (f110_set_map_slot_*, f110_assign_maps) */
 #define F110_MAX_NOISE_SLOTS 64 /* noise slots (= distinct seeds) of one handle (f110_set_noise_generator, f110_assign_noise) */

@@ -353,6 +353,14 @@ extern "C" int f110_create(const f110_config *cfg, f110_handle **out)
     if (cfg->num_envs < 1 || cfg->num_agents < 1 || cfg->num_agents > F110_MAX_AGENTS)
         return fail(F110_E_INVALID, "f110_create: num_envs=%d num_agents=%d out of range (agents 1..%d)",
                     cfg->num_envs, cfg->num_agents, F110_MAX_AGENTS);
+    // Index arithmetic (audited in round 5): every offset that multiplies a car index by a row length (scans, state, pairs,
+    // noise rows) is formed in 64 bits; what stays in 32 bits is the car count itself, wave / thread indices derived from it
+    // (up to 8 waves per car, 4 lanes per (car, opponent) pair, 64 lanes per car) and offsets inside one car's row
+    // (beams * 8 < 2^15).  Hence: cars <= 2^26 and car-opponent pairs <= 2^28.
+    if ((long long)cfg->num_envs * cfg->num_agents > F110_MAX_CARS ||
+        (long long)cfg->num_envs * cfg->num_agents * (cfg->num_agents - 1) > 4ll * F110_MAX_CARS)
+        return fail(F110_E_INVALID, "f110_create: %d envs x %d agents: a handle steps at most %d cars (and %lld car-opponent pairs); shard the batch",
+                    cfg->num_envs, cfg->num_agents, F110_MAX_CARS, 4ll * F110_MAX_CARS);
     if (cfg->num_beams < 2 || cfg->num_beams > 4096 || cfg->theta_dis < 2)
         return fail(F110_E_INVALID, "f110_create: num_beams=%d (2..4096) theta_dis=%d", cfg->num_beams, cfg->theta_dis);
     if (cfg->integrator != F110_RK4 && cfg->integrator != F110_EULER)

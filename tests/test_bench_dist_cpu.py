@@ -48,6 +48,35 @@ def test_two_rank_sharding_and_timing():
     assert ps0 != ps1 and as0 != as1                     # independent shards (different seeds)
 
 
+def _worker_vote(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port), F110_BENCH_TEST_PRIMARY_FAILS='1')
+    import bench
+    ranks = bench.Ranks('gloo', None)           # the primary backend "fails" on rank 1 only
+    e = bench.timed_steps(ranks, lambda k: time.sleep(0.002), 3)
+    q.put((rank, ranks.backend, ranks.dist.get_world_size(), e, ranks.gather_names('r%d' % rank)))
+    ranks.close()
+
+
+def test_backend_fallback_is_decided_by_all_ranks_together():
+    """a rank whose RCCL probe fails must take EVERY rank to the fallback group -- also the ranks whose probe
+    succeeded (they used to stay in the RCCL group, and the first barrier never returned).  The primary backend is made to
+    fail on rank 1 only; both ranks must end up in the same (fallback) group and run the timed region together."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 31700 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker_vote, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[0] for r in res] == [0, 1] and all(r[1] == 'gloo' and r[2] == 2 for r in res)
+    assert res[0][3] == res[1][3] and res[0][4] == res[1][4] == ['r0', 'r1']
+
+
 def test_single_rank_needs_no_process_group():
     sys.path.insert(0, ROOT)
     for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
