@@ -225,6 +225,15 @@ int f110_set_noise_table(f110_handle *h, const double *table_host, int64_t T);
 int f110_set_noise_slot(f110_handle *h, int32_t slot, const double *table_host, int64_t T);
 int f110_set_noise_generator(f110_handle *h, int32_t slot, const uint64_t *pcg64_state_inc, double std_dev);
 int f110_assign_noise(f110_handle *h, const int32_t *slot_of_env_host);
+/* Every env its own seed, any number of them (F110_MAX_NOISE_SLOTS does not apply): pcg64_state_inc_host = [num_envs][4]
+ * {state_lo, state_hi, inc_lo, inc_hi} of np.random.PCG64(seed_e).state['state'].  The env's generator state lives on the
+ * device; the row its scan adds is produced by the step itself, in front of the scan (one wavefront per env and step), into
+ * ONE row per env -- no table to keep ahead of the cars, no floor, no growth: f110_noise_ensure / _prefetch / _set_floor
+ * are no-ops in this mode.  A reset restarts the env's stream at its seed; a row counter that does not continue the
+ * generator's (a loaded checkpoint) makes the generator run forward from the seed without storing.  Costs one more kernel
+ * per step (~1 500 wave-instructions per env).  Setting a table or a slot generator leaves the mode.
+ * Reference: f110_env.py:102-105 (`seed` of every env), base_classes.py:117,202, laser_models.py:450-452. */
+int f110_set_noise_per_env(f110_handle *h, const uint64_t *pcg64_state_inc_host, double std_dev);
 int f110_noise_ensure(f110_handle *h, int64_t rows, void *stream);
 int f110_noise_prefetch(f110_handle *h, int64_t rows);
 int f110_noise_set_floor(f110_handle *h, int64_t lo, void *stream);

@@ -69,6 +69,7 @@ SYMBOLS = {
     'f110_set_noise_slot': [_VP, _I32, _VP, _I64],
     'f110_set_noise_generator': [_VP, _I32, _VP, _D],
     'f110_assign_noise': [_VP, _VP],
+    'f110_set_noise_per_env': [_VP, _VP, _D],
     'f110_noise_ensure': [_VP, _I64, _VP],
     'f110_noise_prefetch': [_VP, _I64],
     'f110_noise_set_floor': [_VP, _I64, _VP],

@@ -116,6 +116,12 @@ struct f110_handle {
     // kernel is enqueued there (it reads and writes the same generator states); the next prefetch waits for it.
     hipEvent_t order_ev = nullptr;
     bool order_ev_set = false;
+    u128 *d_pcg_tab = nullptr;        // [2][65] powers and partial sums of the LCG multiplier (f110_noise.h NoiseGenArgs::pcg_tab)
+    // per-env noise (f110_set_noise_per_env): every env its own generator and ONE row, produced in front of every step's scan
+    bool per_env_noise = false;
+    NoiseGen *d_env_gen = nullptr, *d_env_seed = nullptr;   // [num_envs]
+    double *d_env_rows = nullptr;                           // [num_envs][num_beams]
+    int32_t *d_env_ident = nullptr;                         // [num_envs] env -> slot = env
     NoiseMark *d_marks = nullptr;     // [noise_slots][marks_cap] generator state at every 64th row (f110_noise.h NoiseMark)
     long long marks_cap = 0;
     int marks_slots = 0;
@@ -416,6 +422,8 @@ extern "C" void f110_destroy(f110_handle *h)
     if (h->noise_ev) (void)hipEventDestroy(h->noise_ev);
     if (h->order_ev) (void)hipEventDestroy(h->order_ev);
     if (h->d_marks) (void)hipFree(h->d_marks);
+    for (void *q : {(void *)h->d_pcg_tab, (void *)h->d_env_gen, (void *)h->d_env_seed, (void *)h->d_env_rows, (void *)h->d_env_ident})
+        if (q) (void)hipFree(q);
     if (h->noise_stream) (void)hipStreamDestroy(h->noise_stream);
     for (auto &sl : h->slots)
         for (void *p : {(void *)sl.d_cells, (void *)sl.d_cells_far, (void *)sl.d_lut, (void *)sl.d_lut_lds, (void *)sl.d_dt})
@@ -910,6 +918,12 @@ static void noise_recompute_hi(f110_handle *h)
 static int noise_publish(f110_handle *h, hipStream_t st)
 {
     NoiseDesc d;
+    if (h->per_env_noise) { // one row per env, produced on demand: every row counter is "in the table"
+        d.base = h->d_env_rows; d.cap = 1; d.mask = 0; d.lo = 0; d.hi = 0x7fffffff; d.slots = h->cfg.num_envs; d.pad = 0;
+        hipLaunchKernelGGL(noise_publish_kernel, dim3(1), dim3(1), 0, st, h->d_noise_desc, d);
+        HIP_TRY(hipGetLastError());
+        return F110_OK;
+    }
     d.base = h->d_noise; d.cap = (int)h->noise_cap; d.mask = (int)(h->noise_cap - 1);
     d.lo = h->noise_on ? (int)std::min(h->noise_lo, (long long)0x7fffffff) : 0;
     d.slots = h->noise_slots; d.pad = 0;
@@ -971,6 +985,15 @@ static int noise_init(f110_handle *h)
     HIP_TRY(hipStreamCreateWithFlags(&h->noise_stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&h->noise_ev, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&h->order_ev, hipEventDisableTiming));
+    {   // M^j and 1 + M + ... + M^(j-1), j = 0 .. 64 (mod 2^128)
+        typedef unsigned __int128 u128h;
+        const u128h M = ((u128h)0x2360ED051FC65DA4ull << 64) | (u128h)0x4385DF649FCCF645ull;
+        u128h tab[130];
+        u128h pw = 1, sm = 0;
+        for (int j = 0; j <= 64; j++) { tab[j] = pw; tab[65 + j] = sm; sm = sm * M + 1; pw *= M; }
+        HIP_TRY(hipMalloc((void **)&h->d_pcg_tab, sizeof(tab)));
+        HIP_TRY(hipMemcpy(h->d_pcg_tab, tab, sizeof(tab), hipMemcpyHostToDevice));
+    }
     return noise_resize(h, 1, 1); // noise off: one row of zeros
 }
 
@@ -1022,8 +1045,9 @@ static int noise_launch_generator(f110_handle *h, long long r1, hipStream_t st)
     int rc = noise_marks_reserve(h, r1);
     if (rc) return rc;
     NoiseGenArgs g;
+    memset(&g, 0, sizeof(g));
     g.gen = h->d_noise_gen; g.base = h->d_noise; g.mask = h->noise_cap - 1; g.cap = h->noise_cap; g.lo = h->noise_lo;
-    g.nb = h->cfg.num_beams; g.marks = h->d_marks; g.marks_cap = h->marks_cap; g.redo = 0; g.chunk0 = 0;
+    g.nb = h->cfg.num_beams; g.marks = h->d_marks; g.marks_cap = h->marks_cap; g.redo = 0; g.chunk0 = 0; g.pcg_tab = h->d_pcg_tab;
     for (long long r = (have / NOISE_MARK_ROWS + 1) * NOISE_MARK_ROWS; ; r += NOISE_MARK_ROWS) {
         g.r1 = std::min(r, r1);
         hipLaunchKernelGGL(noise_rows_kernel, dim3(h->noise_slots), dim3(64), 0, st, g);
@@ -1039,8 +1063,9 @@ static int noise_redo_rows(f110_handle *h, long long lo, long long hi, hipStream
 {
     if (hi <= lo) return F110_OK;
     NoiseGenArgs g;
+    memset(&g, 0, sizeof(g));
     g.gen = h->d_noise_gen; g.base = h->d_noise; g.mask = h->noise_cap - 1; g.cap = h->noise_cap; g.lo = lo; g.r1 = hi;
-    g.nb = h->cfg.num_beams; g.marks = h->d_marks; g.marks_cap = h->marks_cap; g.redo = 1; g.chunk0 = lo / NOISE_MARK_ROWS;
+    g.nb = h->cfg.num_beams; g.marks = h->d_marks; g.marks_cap = h->marks_cap; g.redo = 1; g.chunk0 = lo / NOISE_MARK_ROWS; g.pcg_tab = h->d_pcg_tab;
     const long long chunks = (hi + NOISE_MARK_ROWS - 1) / NOISE_MARK_ROWS - g.chunk0;
     for (long long c0 = 0; c0 < chunks; c0 += 32768) { // (grid.y <= 65535)
         NoiseGenArgs gg = g;
@@ -1074,10 +1099,19 @@ static int check_noise_slot(f110_handle *h, int slot, const char *who)
     return F110_OK;
 }
 
+static void leave_per_env_noise(f110_handle *h)
+{
+    if (!h->per_env_noise) return;
+    (void)hipDeviceSynchronize();
+    h->per_env_noise = false;
+    h->epoch++;
+}
+
 extern "C" int f110_set_noise_slot(f110_handle *h, int32_t slot, const double *tbl, int64_t T)
 {
     int rc = check_noise_slot(h, slot, "f110_set_noise_slot");
     if (rc) return rc;
+    leave_per_env_noise(h);
     if (T < 1 || !tbl) return fail(F110_E_INVALID, "f110_set_noise_slot: bad table (T >= 1 rows; f110_set_noise_table(h, NULL, 0) switches noise off)");
     ON_DEVICE(h->cfg.device);
     const int nb = h->cfg.num_beams;
@@ -1119,6 +1153,7 @@ extern "C" int f110_set_noise_table(f110_handle *h, const double *tbl, int64_t T
     if (T > 0) return f110_set_noise_slot(h, 0, tbl, T);
     // noise off: every slot forgets its table / generator
     ON_DEVICE(h->cfg.device);
+    leave_per_env_noise(h);
     HIP_TRY(hipStreamSynchronize(h->noise_stream));
     h->noise_pending_hi = 0;
     for (auto &ns : h->nslots) { ns.kind = 0; ns.rows.clear(); ns.rows.shrink_to_fit(); ns.T = 0; }
@@ -1136,6 +1171,7 @@ extern "C" int f110_set_noise_generator(f110_handle *h, int32_t slot, const uint
     if (!pcg64 || !(std_dev >= 0) || !std::isfinite(std_dev)) return fail(F110_E_INVALID, "f110_set_noise_generator: bad arguments");
     if (!(pcg64[2] & 1ull)) return fail(F110_E_INVALID, "f110_set_noise_generator: the PCG64 increment must be odd");
     ON_DEVICE(h->cfg.device);
+    leave_per_env_noise(h);
     HIP_TRY(hipStreamSynchronize(h->noise_stream));
     HIP_TRY(hipDeviceSynchronize());
     auto &ns = h->nslots[slot];
@@ -1164,9 +1200,52 @@ extern "C" int f110_set_noise_generator(f110_handle *h, int32_t slot, const uint
     return noise_publish_cold(h);
 }
 
+// Every env its own stream (reference: every F110Env is constructed with its own `seed`, f110_env.py:102-105; its cars re-create
+// default_rng(seed) at every reset, base_classes.py:117,202).  No table of rows per seed and no limit on the number of seeds:
+// an env's generator state lives on the device and the row its scan adds is produced in front of the scan, every step
+// (noise_rows_kernel in per-env mode, one wavefront per env).  pcg64 = host [num_envs][4] {state_lo, state_hi, inc_lo, inc_hi}.
+extern "C" int f110_set_noise_per_env(f110_handle *h, const uint64_t *pcg64, double std_dev)
+{
+    if (!h || !pcg64 || !(std_dev >= 0) || !std::isfinite(std_dev)) return fail(F110_E_INVALID, "f110_set_noise_per_env: bad arguments");
+    const int B = h->cfg.num_envs, nb = h->cfg.num_beams;
+    std::vector<NoiseGen> seeds((size_t)B);
+    typedef unsigned __int128 u128h;
+    const u128h M = ((u128h)0x2360ED051FC65DA4ull << 64) | (u128h)0x4385DF649FCCF645ull;
+    for (int e = 0; e < B; e++) {
+        const uint64_t *w = pcg64 + (size_t)e * 4;
+        if (!(w[2] & 1ull)) return fail(F110_E_INVALID, "f110_set_noise_per_env: env %d: the PCG64 increment must be odd", e);
+        const u128h st = ((u128h)w[1] << 64) | w[0], inc = ((u128h)w[3] << 64) | w[2];
+        const u128h t = st * M + inc; // the state whose output is the first raw value (pcg64.h: step, then output)
+        NoiseGen &g = seeds[(size_t)e];
+        memset(&g, 0, sizeof(g));
+        g.t_lo = (unsigned long long)t; g.t_hi = (unsigned long long)(t >> 64); g.inc_lo = w[2]; g.inc_hi = w[3];
+        g.std = std_dev; g.rows = 0; g.on = 1;
+    }
+    ON_DEVICE(h->cfg.device);
+    HIP_TRY(hipStreamSynchronize(h->noise_stream));
+    HIP_TRY(hipDeviceSynchronize());
+    if (!h->d_env_gen) {
+        HIP_TRY(hipMalloc((void **)&h->d_env_gen, sizeof(NoiseGen) * (size_t)B));
+        HIP_TRY(hipMalloc((void **)&h->d_env_seed, sizeof(NoiseGen) * (size_t)B));
+        HIP_TRY(hipMalloc((void **)&h->d_env_rows, sizeof(double) * (size_t)B * nb));
+        HIP_TRY(hipMalloc((void **)&h->d_env_ident, sizeof(int32_t) * (size_t)B));
+        std::vector<int32_t> id((size_t)B);
+        for (int e = 0; e < B; e++) id[(size_t)e] = e;
+        HIP_TRY(hipMemcpy(h->d_env_ident, id.data(), sizeof(int32_t) * (size_t)B, hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipMemcpy(h->d_env_seed, seeds.data(), sizeof(NoiseGen) * (size_t)B, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->d_env_gen, seeds.data(), sizeof(NoiseGen) * (size_t)B, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(h->d_env_rows, 0, sizeof(double) * (size_t)B * nb));
+    h->per_env_noise = true;
+    h->noise_on = true;
+    h->epoch++;
+    return noise_publish_cold(h);
+}
+
 extern "C" int f110_noise_prefetch(f110_handle *h, int64_t rows)
 {
     if (!h) return fail(F110_E_INVALID, "f110_noise_prefetch: null handle");
+    if (h->per_env_noise) return F110_OK;
     if (!h->noise_on || !noise_has_generators(h) || h->noise_pending_hi) return F110_OK;
     long long have = 0x7fffffffffffffffll;
     for (int sl = 0; sl < h->noise_slots; sl++)
@@ -1188,7 +1267,7 @@ extern "C" int f110_noise_prefetch(f110_handle *h, int64_t rows)
 extern "C" int f110_noise_ensure(f110_handle *h, int64_t rows, void *stream)
 {
     if (!h) return fail(F110_E_INVALID, "f110_noise_ensure: null handle");
-    if (!h->noise_on || rows <= h->noise_hi) return F110_OK;
+    if (h->per_env_noise || !h->noise_on || rows <= h->noise_hi) return F110_OK; // (per-env rows are produced by the step itself)
     if (int rc = check_device(h, "f110_noise_ensure")) return rc;
     hipStream_t st = (hipStream_t)stream;
     noise_reap(h, false);
@@ -1215,7 +1294,7 @@ extern "C" int f110_noise_ensure(f110_handle *h, int64_t rows, void *stream)
 extern "C" int f110_noise_set_floor(f110_handle *h, int64_t lo, void *stream)
 {
     if (!h || lo < 0) return fail(F110_E_INVALID, "f110_noise_set_floor: bad arguments");
-    if (!h->noise_on || lo == h->noise_lo) return F110_OK;
+    if (h->per_env_noise || !h->noise_on || lo == h->noise_lo) return F110_OK;
     if (int rc = check_device(h, "f110_noise_set_floor")) return rc;
     if (lo > h->noise_lo) {
         for (int sl = 0; sl < h->noise_slots; sl++)
@@ -1570,6 +1649,7 @@ static void fill_scan_args(const f110_handle *h, ScanArgs &s, int reset_only)
     s.side = h->d_side; s.side_max = h->side_max;
     s.noise_base = h->d_noise; s.noise_cap = (int)h->noise_cap; s.noise_mask = (int)(h->noise_cap - 1); s.noise_slots = h->noise_slots;
     s.env_noise = h->multi_noise ? h->d_env_noise : nullptr; s.dev_err = h->d_err;
+    if (h->per_env_noise) { s.noise_base = h->d_env_rows; s.noise_cap = 1; s.noise_mask = 0; s.noise_slots = c.num_envs; s.env_noise = h->d_env_ident; }
     s.beam_cosines = h->d_beam_cosines; s.ttc_thresh = c.ttc_thresh;
     s.in_collision = b.in_collision; s.pending_reset = b.pending_reset; s.reset_only = reset_only;
     s.out_f32 = b.scans; s.out_f64 = b.scans_f64; s.lookups = b.lookups;
@@ -1597,6 +1677,15 @@ static int run_step(f110_handle *h, const double *actions, int reset_only, const
     hipEvent_t ev0 = prof ? h->prof_ev[2 * h->prof_n] : nullptr, ev1 = prof ? h->prof_ev[2 * h->prof_n + 1] : nullptr;
     int rc;
 
+    if (h->per_env_noise) {
+        // the row every env's scan is about to add (row `pending ? 0 : noise_step`), from the env's own generator
+        NoiseGenArgs g;
+        memset(&g, 0, sizeof(g));
+        g.gen = h->d_env_gen; g.seeds = h->d_env_seed; g.base = h->d_env_rows; g.mask = 0; g.cap = 1; g.nb = c.num_beams;
+        g.pcg_tab = h->d_pcg_tab; g.env_row = b.noise_step; g.env_row_stride = c.num_agents; g.n_env = c.num_envs;
+        g.reset_only = reset_only; g.env_pending = b.pending_reset;
+        if ((rc = emit(st, (const void *)&noise_rows_kernel, dim3((c.num_envs + 3) / 4), dim3(256), 0, g))) return rc;
+    }
     {
         DynArgs d;
         d.n_cars = N; d.agents = c.num_agents; d.state = b.state; d.steer_buf = b.steer_buf; d.steer_cnt = b.steer_cnt;

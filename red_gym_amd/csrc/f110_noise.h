@@ -155,6 +155,18 @@ struct NoiseGenArgs {
     // marks[slot][chunk0 + y]; the generators' own states are neither read nor written
     int redo;
     long long chunk0;
+    // powers and partial sums of the LCG multiplier: pcg_tab[j] = M^j, pcg_tab[65 + j] = 1 + M + ... + M^(j-1), j = 0 .. 64
+    // (f110_abi.hip computes them once): lane j's start state and the 64-step jump are two multiply-adds instead of loops
+    const u128 *pcg_tab;
+    // PER-ENV mode (f110_set_noise_per_env: every env its own seed, no limit on their number): slot = env, the table holds ONE
+    // row per env (cap = 1), and every step produces the row the env's scan is about to add -- row `pend ? 0 : env_row[slot *
+    // env_row_stride]` of the env's stream -- from the state the previous step left (or from the seed after a reset; or, after
+    // a checkpoint was loaded, by running the stream forward from the seed without storing).  blockDim = 64 * waves, one
+    // wavefront per env.
+    const int32_t *env_row;
+    int env_row_stride, n_env, reset_only;
+    const uint8_t *env_pending;
+    const NoiseGen *seeds;
 };
 
 // One wavefront per noise slot (grid = slots).
@@ -167,12 +179,23 @@ struct NoiseGenArgs {
 // into the next window if need be: `skip`), everything else is.  The accepted candidates are numbered by a prefix count and
 // stored as consecutive beams.  The window then advances by exactly 64 positions (one 128-bit multiply-add per lane), so
 // there is no re-basing shuffle and the only state carried from window to window is (skip, beams produced).
-__global__ __launch_bounds__(64) void noise_rows_kernel(NoiseGenArgs a)
+__global__ __launch_bounds__(256) void noise_rows_kernel(NoiseGenArgs a)
 {
     __shared__ unsigned long long s_ki[256];
     __shared__ double s_wi[256], s_fi[256];
-    const int lane = threadIdx.x, slot = blockIdx.x;
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) { s_ki[i] = ZIG_KI[i]; s_wi[i] = ZIG_WI[i]; s_fi[i] = ZIG_FI[i]; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int slot = a.env_row ? blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6) : blockIdx.x;
+    if (a.env_row && slot >= a.n_env) return;
     NoiseGen g = a.gen[slot];
+    if (a.env_row) {
+        const bool pend = a.env_pending && a.env_pending[slot];
+        if (a.reset_only && !pend) return;
+        const long long r = pend ? 0 : (long long)a.env_row[(size_t)slot * (size_t)a.env_row_stride];
+        if (r <= 0 || g.rows > r) { const NoiseGen sd = a.seeds[slot]; g.t_lo = sd.t_lo; g.t_hi = sd.t_hi; g.rows = 0; }
+        a.lo = r < 0 ? 0 : r; a.r1 = a.lo + 1;
+    }
     if (a.redo) {
         const long long ch = a.chunk0 + blockIdx.y;
         if (!g.on || !a.marks || ch >= a.marks_cap) return;
@@ -180,20 +203,17 @@ __global__ __launch_bounds__(64) void noise_rows_kernel(NoiseGenArgs a)
         g.t_lo = mk.t_lo; g.t_hi = mk.t_hi; g.rows = ch * NOISE_MARK_ROWS;
         a.r1 = a.r1 < g.rows + NOISE_MARK_ROWS ? a.r1 : g.rows + NOISE_MARK_ROWS;
     }
-    if (!g.on || g.rows >= a.r1) return; // (uniform)
+    if (!g.on || g.rows >= a.r1) return; // (wave-uniform)
     // the mark of the row this launch starts at (a launch ends where the next one starts: every multiple of 64 rows gets one)
     if (!a.redo && a.marks && lane == 0 && g.rows % NOISE_MARK_ROWS == 0 && g.rows / NOISE_MARK_ROWS < a.marks_cap) {
         NoiseMark mk; mk.t_lo = g.t_lo; mk.t_hi = g.t_hi;
         a.marks[(size_t)slot * (size_t)a.marks_cap + (size_t)(g.rows / NOISE_MARK_ROWS)] = mk;
     }
-    for (int i = lane; i < 256; i += 64) { s_ki[i] = ZIG_KI[i]; s_wi[i] = ZIG_WI[i]; s_fi[i] = ZIG_FI[i]; }
-    __syncthreads();
     const u128 M = pcg_mult(), inc = ((u128)g.inc_hi << 64) | (u128)g.inc_lo;
-    // 64 steps at once: s -> A * s + C
-    u128 A = 1, C = 0;
-    for (int i = 0; i < 64; i++) { A *= M; C = C * M + inc; }
+    // 64 steps at once: s -> A * s + C, A = M^64, C = (1 + M + ... + M^63) * inc
+    const u128 A = a.pcg_tab[64], C = a.pcg_tab[65 + 64] * inc;
     u128 T = ((u128)g.t_hi << 64) | (u128)g.t_lo;
-    for (int i = 0; i < lane; i++) T = T * M + inc; // lane j: the state whose output is raw value p + j
+    T = a.pcg_tab[lane] * T + a.pcg_tab[65 + lane] * inc; // lane j: the state whose output is raw value p + j (j LCG steps ahead)
     const double std = g.std;
     const int nb = a.nb;
     const unsigned long long below = (1ull << lane) - 1ull;

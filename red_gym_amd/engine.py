@@ -100,14 +100,19 @@ class Engine(object):
                  ttc_thresh=0.005, device=0, autoreset=False, noise_std=0.01, noise_steps=0,
                  keep_f64_scans=False, count_lookups=False, noise_source='device'):
         """`params`: one dict (every env, f110_env.py:125-128) or a sequence of num_envs dicts (env e constructed with
-        params[e]); `seed`: one int (:102-105) or a sequence of num_envs ints (at most F110_MAX_NOISE_SLOTS distinct).
-        `noise_source`: 'device' (rows produced on the GPU) or 'numpy' (NumPy draws on the host, rows uploaded);
+        params[e]); `seed`: one int (:102-105) or a sequence of num_envs ints.
+        `noise_source`: 'device' (rows produced on the GPU, kept once per distinct seed in a table that runs ahead of the
+        cars: at most F110_MAX_NOISE_SLOTS distinct seeds), 'per_env' (every env its own generator, its row produced by the
+        step itself: any number of seeds -- chosen by itself when 'device' is asked for more distinct seeds than the table
+        holds) or 'numpy' (NumPy draws on the host, rows uploaded);
         `noise_steps`: rows to have ready at construction (0: the first step asks for them)."""
         if not torch.cuda.is_available():
             raise RuntimeError('red_gym_amd needs a HIP device (torch.cuda.is_available() is False); '
                                'there is no CPU path.')
-        if noise_source not in ('device', 'numpy'):
-            raise ValueError("noise_source must be 'device' or 'numpy'")
+        if noise_source == 'per_car':
+            noise_source = 'per_env'   # (the cars of an env share its seed and therefore its rows)
+        if noise_source not in ('device', 'numpy', 'per_env'):
+            raise ValueError("noise_source must be 'device', 'per_env' or 'numpy'")
         self.lib = _lib.load()
         env_params = None
         if params is not None and not isinstance(params, dict):
@@ -151,6 +156,7 @@ class Engine(object):
         self._steps_exact = False
         self._noise_on = bool(noise_std and noise_std > 0)
         self._noise_gen = self._noise_on and noise_source == 'device'
+        self._noise_per_env = self._noise_on and noise_source == 'per_env'
         self._noise_rows, self._noise_floor, self._noise_prefetched = 0, 0, False
         self._in_capture = False  # a stream capture is recording step(): no noise work (it was done in front of the capture)
         self.noise_tables = []
@@ -211,12 +217,26 @@ class Engine(object):
 
     def _setup_noise(self, seeds, std):
         """One noise slot per distinct seed (base_classes.py:117,202: all cars of an env draw from default_rng(seed))."""
-        uniq = []
-        for sd in seeds:
-            if sd not in uniq:
-                uniq.append(sd)
+        uniq = list(dict.fromkeys(seeds))
+        if len(uniq) > _lib.F110_MAX_NOISE_SLOTS and self._noise_gen:
+            self._noise_gen, self._noise_per_env = False, True   # more seeds than the table has slots: every env its own generator
+        if self._noise_per_env:
+            # f110_env.py:102-105: every env its own `seed`; np.random.PCG64(seed).state is the stream default_rng(seed) starts from
+            m64 = (1 << 64) - 1
+            words = np.empty((self.B, 4), dtype=np.uint64)
+            per_seed = {}
+            for e in range(self.B):
+                sd = seeds[e if len(seeds) > 1 else 0]
+                if sd not in per_seed:
+                    st = np.random.PCG64(sd).state['state']
+                    per_seed[sd] = (st['state'] & m64, st['state'] >> 64, st['inc'] & m64, st['inc'] >> 64)
+                words[e] = per_seed[sd]
+            _lib.check(self.lib.f110_set_noise_per_env(self._h, _np_ptr(words), std))
+            self.noise_seeds, self._noise_std = uniq, std
+            return
         if len(uniq) > _lib.F110_MAX_NOISE_SLOTS:
-            raise ValueError('%d distinct seeds; a handle holds %d noise slots' % (len(uniq), _lib.F110_MAX_NOISE_SLOTS))
+            raise ValueError("%d distinct seeds; a table of host rows holds %d noise slots (noise_source='per_env' has no limit)"
+                             % (len(uniq), _lib.F110_MAX_NOISE_SLOTS))
         self.noise_seeds, self._noise_std = uniq, std
         for k, sd in enumerate(uniq):
             if self._noise_gen:
@@ -253,6 +273,8 @@ class Engine(object):
 
     def _noise_to(self, rows):
         """Rows 0 .. rows-1 (above the floor) readable by the steps enqueued from now on."""
+        if self._noise_per_env:
+            return
         if self._noise_gen:
             _lib.check(self.lib.f110_noise_ensure(self._h, int(rows), self._stream()))
             self._noise_rows = self.noise_info()[1]  # (host-side bookkeeping of the library: no synchronisation)
@@ -279,8 +301,8 @@ class Engine(object):
         the next chunk would not fit the table and cars cannot go back to row 0 by themselves (autoreset off), the floor
         moves up to the slowest car instead of the table growing (a ring of constant size however long the run), and the
         next chunk is produced.  may_raise_floor=False: a reset is about to send cars back to row 0."""
-        if not self._noise_on or self._in_capture:
-            return
+        if not self._noise_on or self._in_capture or self._noise_per_env:
+            return   # (per-env noise: the step produces its own rows)
         need = self.host_steps_bound + 2
         if need <= self._noise_rows:
             if self._noise_gen and not self._noise_prefetched and need + self.NOISE_CHUNK // 2 > self._noise_rows:

@@ -102,6 +102,81 @@ def test_k_seeds_and_k_vehicles_are_k_reference_envs(assets, source):
     env.close()
 
 
+def test_every_env_its_own_seed_4096_envs_are_4096_reference_envs(assets):
+    """`F110VecEnv(seed=list(...))` with MORE distinct seeds than the noise table has slots -- 4 096 envs,
+    4 096 seeds (f110_env.py:102-105: every env is constructed with its own seed) -- runs with one generator per env
+    (noise_source 'per_env', chosen by itself here), and every env `==` its own oracle Env fed NumPy's rows for that seed
+    (default_rng(seed).normal, base_classes.py:117,202; laser_models.py:450-452), 24 steps through wall hits and autoresets
+    (state / scans 1e-9; the noise itself bit for bit: a parked car's scan IS its row)."""
+    import torch
+    from red_gym_amd import F110VecEnv, workload
+    B, A, T = 4096, 1, 24
+    seeds = [1000 + 7 * e for e in range(B)]
+    env = F110VecEnv(B, map=os.path.join(assets, 'example_map'), num_agents=A, seed=seeds, autoreset=True, keep_f64_scans=True)
+    assert env.eng._noise_per_env and env.eng.noise_info()[3] in (1, B)
+    sc = _scanner(assets)
+    ors = [oracle.Env(sc, A, noise=oracle.noise_table(sd, T + 4)) for sd in seeds]
+    poses = workload.spawn_poses(B, A)
+    poses[:8] = np.array([[-45.87478769831466, -16.282154624538293, 0.3]])      # inside a wall: the scan is the noise row
+    acts = workload.action_pool(8, B, A)
+    acts[:, 100:600, :, 0] = 0.35
+    acts[:, 100:600, :, 1] = 7.0     # these steer into the wall: iTTC hit, done, autoreset -> their streams restart
+    env.reset(poses)
+    oo = [ors[e].reset(poses[e]) for e in range(B)]
+    pend = np.zeros(B, dtype=bool)
+    dones = 0
+    for k in range(T):
+        obs, _, done, info = env.step(torch.as_tensor(acts[k % 8], device='cuda'))
+        st, sc64, dn = _np(env.state), _np(obs['scans_f64']), _np(done).astype(bool)
+        for e in range(B):
+            oo[e] = ors[e].reset(poses[e]) if pend[e] else ors[e].step(acts[k % 8][e])
+        want_st = np.stack([o['state'] for o in oo]); want_sc = np.stack([o['scans'] for o in oo])
+        assert np.allclose(st, want_st, rtol=0, atol=1e-9), k
+        assert np.allclose(sc64, want_sc, rtol=0, atol=1e-9), k
+        assert np.array_equal(sc64[:8], want_sc[:8]), k                 # noise rows: NumPy's bits
+        assert np.array_equal(dn, np.array([o['done'] for o in oo])), k
+        pend = dn
+        dones += int(pend.sum())
+    assert dones > 100 and env.eng.device_errors() == 0
+    assert not np.array_equal(sc64[0], sc64[1])
+    env.close()
+
+
+def test_per_env_noise_follows_a_loaded_checkpoint_and_a_masked_reset(assets):
+    """Per-env generators keep no table: a row counter that does not continue the generator's (state restored from a
+    checkpoint) makes the generator run forward from its seed; a masked reset restarts only the masked envs' streams."""
+    import torch
+    from red_gym_amd import F110VecEnv
+    B = 6
+    seeds = [3, 4, 5, 3, 4, 5]
+    env = F110VecEnv(B, map=os.path.join(assets, 'example_map'), num_agents=1, seed=seeds, autoreset=False, keep_f64_scans=True,
+                     noise_source='per_env')
+    poses = np.tile(np.array([[[-45.87478769831466, -16.282154624538293, 0.3]]]), (B, 1, 1))   # inside a wall
+    z = torch.zeros((B, 1, 2), dtype=torch.float64, device='cuda')
+    env.reset(poses)
+    for k in range(40):
+        env.step(z)
+    sd = env.state_dict()
+    for k in range(5):
+        env.step(z)
+    s45 = _np(env.eng.t['scans_f64']).copy()
+    env.load_state_dict(sd)                      # back to row 41: the generators stand at 46
+    for k in range(5):
+        env.step(z)
+    assert np.array_equal(_np(env.eng.t['scans_f64']), s45)
+    rows = {s_: np.random.default_rng(s_).normal(0., 0.01, size=(60, 1080)) for s_ in (3, 4, 5)}
+    assert np.array_equal(s45[:, 0], np.stack([rows[s_][45] for s_ in seeds]))
+    m = torch.zeros(B, dtype=torch.uint8, device='cuda'); m[1] = 1; m[5] = 1
+    env.reset(poses, m)
+    got = _np(env.eng.t['scans_f64'])[:, 0]
+    assert np.array_equal(got[1], rows[4][0]) and np.array_equal(got[5], rows[5][0])
+    env.step(z)
+    got = _np(env.eng.t['scans_f64'])[:, 0]
+    want = np.stack([rows[seeds[e]][1 if e in (1, 5) else 46] for e in range(B)])
+    assert np.array_equal(got, want) and env.eng.device_errors() == 0
+    env.close()
+
+
 def test_update_params_reaches_every_slot_and_one_slot_only(assets):
     """f110_update_params (Simulator.update_params, base_classes.py:507-527) applies to the agent in EVERY env;
     f110_set_params_slot(slot, agent) to that env's agent only; IndexError beyond the agent list."""
@@ -358,7 +433,10 @@ def test_slot_api_refuses_what_it_cannot_do(assets):
     from red_gym_amd import F110VecEnv, _lib
     from red_gym_amd.engine import DEFAULT_PARAMS, Engine, params_vec
     with pytest.raises(ValueError):
-        Engine(num_envs=100, seed=list(range(100)))                       # 100 distinct seeds > 64 noise slots
+        Engine(num_envs=100, seed=list(range(100)), noise_source='numpy')  # 100 distinct seeds > 64 slots of host rows
+    e100 = Engine(num_envs=100, seed=list(range(100)))                    # ... the device switches to one generator per env
+    assert e100._noise_per_env
+    e100.close()
     with pytest.raises(ValueError):
         Engine(num_envs=4, seed=[1, 2, 3])                                # one seed per env
     with pytest.raises(ValueError):
