@@ -318,6 +318,15 @@ int f110_profile_end(f110_handle *h, double *scan_ms_total, int32_t *launches);
  * dev [M,3] (x, y, speed); state: dev [n,7] (f110_buffers.state); writes actions dev [n,2]
  * = (steer, vgain*speed), ready to be passed to f110_step.  The planner keeps no state: h may be NULL (the
  * kernel is then enqueued on `stream` of the calling thread's current device). */
+/* Optional: PREPARES one raceline (dev [M,3], M <= 65 535) for f110_pure_pursuit -- a grid of `cell` metres (0: 0.25) reaching
+ * `margin` metres (0: 3) around the raceline whose cells list the segments that can be the nearest one for any pose in the cell
+ * (conservative: every segment within 2 half-diagonals of the cell centre's nearest).  f110_pure_pursuit(h, the same pointer,
+ * the same M, ...) then plans with ONE LANE per car over that list instead of one wavefront per car over 64-segment blocks
+ * (65 536 cars on the 783-point example raceline: see profiles/r05_planner.txt); poses outside the grid, NaN poses and
+ * cells with more than 30 candidates take every segment -- the results are the same in every case (tests: `==` both
+ * kernels and oracle/planner.py).  A cold path (copies the raceline to the host, synchronises); call it again when the raceline's
+ * VALUES change.  Reference: examples/waypoint_follow.py:15-47 (nearest point), :183-217 (plan). */
+int f110_pure_pursuit_prepare(f110_handle *h, const double *waypoints, int32_t M, double cell, double margin, void *stream);
 int f110_pure_pursuit(f110_handle *h, const double *waypoints, int32_t M, double lookahead, double vgain,
                       double wheelbase, double max_reacquire, const double *state, int32_t n,
                       double *actions, void *stream);

@@ -88,6 +88,7 @@ SYMBOLS = {
     'f110_graph_info': [_VP, C.POINTER(C.c_int32), C.c_char_p],
     'f110_graph_destroy': [_VP],
     'f110_pure_pursuit': [_VP, _VP, _I32, _D, _D, _D, _D, _VP, _I32, _VP, _VP],
+    'f110_pure_pursuit_prepare': [_VP, _VP, _I32, _D, _D, _VP],
     'f110_pure_pursuit_workspace': [_I32, _I32],
     'f110_pure_pursuit_tracks': [_VP, _VP, _VP, _VP, _I32, _VP, _D, _D, _D, _D, _VP, _I32, _VP, _VP, _I32, _VP],
     'f110_profile_begin': [_VP, _I32],

@@ -116,6 +116,10 @@ struct f110_handle {
     // kernel is enqueued there (it reads and writes the same generator states); the next prefetch waits for it.
     hipEvent_t order_ev = nullptr;
     bool order_ev_set = false;
+    // prepared raceline of f110_pure_pursuit (f110_pure_pursuit_prepare): grid of candidate lists (f110_planner.h PlanGrid)
+    const double *plan_wp = nullptr; int plan_M = 0; bool plan_ok = false;
+    PlanGrid plan_grid;
+    uint8_t *d_plan_count = nullptr; uint16_t *d_plan_cand = nullptr;
     u128 *d_pcg_tab = nullptr;        // [2][65] powers and partial sums of the LCG multiplier (f110_noise.h NoiseGenArgs::pcg_tab)
     // per-env noise (f110_set_noise_per_env): every env its own generator and ONE row, produced in front of every step's scan
     bool per_env_noise = false;
@@ -422,7 +426,7 @@ extern "C" void f110_destroy(f110_handle *h)
     if (h->noise_ev) (void)hipEventDestroy(h->noise_ev);
     if (h->order_ev) (void)hipEventDestroy(h->order_ev);
     if (h->d_marks) (void)hipFree(h->d_marks);
-    for (void *q : {(void *)h->d_pcg_tab, (void *)h->d_env_gen, (void *)h->d_env_seed, (void *)h->d_env_rows, (void *)h->d_env_ident})
+    for (void *q : {(void *)h->d_plan_count, (void *)h->d_plan_cand, (void *)h->d_pcg_tab, (void *)h->d_env_gen, (void *)h->d_env_seed, (void *)h->d_env_rows, (void *)h->d_env_ident})
         if (q) (void)hipFree(q);
     if (h->noise_stream) (void)hipStreamDestroy(h->noise_stream);
     for (auto &sl : h->slots)
@@ -2015,6 +2019,83 @@ static int32_t *single_track_offsets(int dev, int M)
     return d.hdr;
 }
 
+// Builds the grid of candidate lists for one raceline (dev [M,3]) in the handle: a cold path (the raceline is copied to the host,
+// ~0.1 s for the 783-point example raceline).  The caller promises to call it again when the raceline's values change; the pointer
+// and M are what f110_pure_pursuit matches.  cell: edge of a grid cell in metres (0: 0.25); margin: how far around the raceline's
+// bounding box the grid reaches (0: 3 m) -- poses beyond it are planned by the exhaustive search.
+extern "C" int f110_pure_pursuit_prepare(f110_handle *h, const double *waypoints, int32_t M, double cell, double margin, void *stream)
+{
+    if (!h || !waypoints) return fail(F110_E_INVALID, "f110_pure_pursuit_prepare: null argument");
+    if (int rc = check_device(h, "f110_pure_pursuit_prepare")) return rc;
+    h->plan_ok = false;
+    if (M < 2 || M > 65535) return fail(F110_E_INVALID, "f110_pure_pursuit_prepare: M=%d waypoints (2..65535)", M);
+    if (!(cell >= 0) || !(margin >= 0) || !std::isfinite(cell) || !std::isfinite(margin)) return fail(F110_E_INVALID, "f110_pure_pursuit_prepare: bad cell / margin");
+    if (cell == 0) cell = 0.25;
+    if (margin == 0) margin = 3.0;
+    std::vector<double> wp((size_t)M * 3);
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    HIP_TRY(hipMemcpy(wp.data(), waypoints, wp.size() * sizeof(double), hipMemcpyDeviceToHost));
+    const int nseg = M - 1;
+    double xl = 1e300, xh = -1e300, yl = 1e300, yh = -1e300;
+    bool finite = true, degenerate = false;
+    for (int i = 0; i < M; i++) {
+        const double x = wp[3 * (size_t)i], y = wp[3 * (size_t)i + 1];
+        finite = finite && std::isfinite(x) && std::isfinite(y);
+        xl = std::min(xl, x); xh = std::max(xh, x); yl = std::min(yl, y); yh = std::max(yh, y);
+    }
+    if (!finite) return fail(F110_E_INVALID, "f110_pure_pursuit_prepare: the raceline has non-finite points");
+    for (int i = 0; i < nseg; i++) {
+        const double dx = wp[3 * (size_t)i + 3] - wp[3 * (size_t)i], dy = wp[3 * (size_t)i + 4] - wp[3 * (size_t)i + 1];
+        if (dx * dx + dy * dy == 0.0) degenerate = true;
+    }
+    PlanGrid g;
+    memset(&g, 0, sizeof(g));
+    g.x0 = xl - margin; g.y0 = yl - margin; g.inv_cell = 1.0 / cell;
+    const double gw = std::ceil((xh + margin - g.x0) / cell), gh = std::ceil((yh + margin - g.y0) / cell);
+    if (!(gw >= 1 && gh >= 1) || gw * gh > 16.0e6) return fail(F110_E_INVALID, "f110_pure_pursuit_prepare: grid of %.0f x %.0f cells (choose a larger cell)", gw, gh);
+    g.gw = (int)gw; g.gh = (int)gh; g.degenerate = degenerate ? 1 : 0;
+    const size_t cells = (size_t)g.gw * g.gh;
+    std::vector<uint8_t> count(cells, 0);
+    std::vector<uint16_t> cand(cells * PG_CAP, 0);
+    if (!degenerate) {
+        // segments bucketed by a coarse grid first, so that a cell only looks at the segments that can matter
+        const double hd = 0.5 * cell * std::sqrt(2.0);
+        auto seg_dist = [&](int i, double px, double py) {
+            const double x0 = wp[3 * (size_t)i], y0 = wp[3 * (size_t)i + 1];
+            const double dx = wp[3 * (size_t)i + 3] - x0, dy = wp[3 * (size_t)i + 4] - y0;
+            const double l2 = dx * dx + dy * dy;
+            double t = ((px - x0) * dx + (py - y0) * dy) / l2;
+            t = t < 0.0 ? 0.0 : t; t = t > 1.0 ? 1.0 : t;
+            const double qx = px - (x0 + t * dx), qy = py - (y0 + t * dy);
+            return std::sqrt(qx * qx + qy * qy);
+        };
+        std::vector<double> dist((size_t)nseg);
+        for (int iy = 0; iy < g.gh; iy++)
+            for (int ix = 0; ix < g.gw; ix++) {
+                const double cx = g.x0 + (ix + 0.5) * cell, cy = g.y0 + (iy + 0.5) * cell;
+                double D = 1e300;
+                for (int i = 0; i < nseg; i++) { dist[(size_t)i] = seg_dist(i, cx, cy); D = std::min(D, dist[(size_t)i]); }
+                const double lim = D + 2.0 * hd + 1e-6;
+                unsigned n = 0;
+                const size_t c = (size_t)iy * g.gw + ix;
+                for (int i = 0; i < nseg && n <= (unsigned)PG_CAP; i++)
+                    if (dist[(size_t)i] <= lim) { if (n < (unsigned)PG_CAP) cand[c * PG_CAP + n] = (uint16_t)i; n++; }
+                count[c] = n > (unsigned)PG_CAP ? (uint8_t)PG_ALL : (uint8_t)n;
+            }
+    }
+    ON_DEVICE(h->cfg.device);
+    HIP_TRY(hipDeviceSynchronize()); // an enqueued plan may still read the previous grid
+    if (h->d_plan_count) { (void)hipFree(h->d_plan_count); h->d_plan_count = nullptr; }
+    if (h->d_plan_cand) { (void)hipFree(h->d_plan_cand); h->d_plan_cand = nullptr; }
+    HIP_TRY(hipMalloc((void **)&h->d_plan_count, cells));
+    HIP_TRY(hipMalloc((void **)&h->d_plan_cand, cells * PG_CAP * sizeof(uint16_t)));
+    HIP_TRY(hipMemcpy(h->d_plan_count, count.data(), cells, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->d_plan_cand, cand.data(), cells * PG_CAP * sizeof(uint16_t), hipMemcpyHostToDevice));
+    g.count = h->d_plan_count; g.cand = h->d_plan_cand;
+    h->plan_grid = g; h->plan_wp = waypoints; h->plan_M = M; h->plan_ok = true;
+    return F110_OK;
+}
+
 extern "C" int f110_pure_pursuit(f110_handle *h, const double *waypoints, int32_t M, double lookahead, double vgain,
                                  double wheelbase, double max_reacquire, const double *state, int32_t n,
                                  double *actions, void *stream)
@@ -2025,6 +2106,15 @@ extern "C" int f110_pure_pursuit(f110_handle *h, const double *waypoints, int32_
     if (h) if (int rc = check_device(h, "f110_pure_pursuit")) return rc;
     if (!waypoints || !state || !actions) return fail(F110_E_INVALID, "f110_pure_pursuit: null pointer");
     if (M < 2) return fail(F110_E_INVALID, "f110_pure_pursuit: M=%d waypoints (a raceline has at least 2)", M);
+    if (h && h->plan_ok && h->plan_wp == waypoints && h->plan_M == M) {
+        // a prepared raceline: one lane per car over the grid's candidate lists
+        PlanArgs a;
+        a.waypoints = waypoints; a.M = M; a.lookahead = lookahead; a.vgain = vgain; a.wheelbase = wheelbase;
+        a.max_reacquire = max_reacquire; a.state = state; a.n = n; a.actions = actions;
+        hipLaunchKernelGGL(pure_pursuit_grid_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, h->plan_grid);
+        HIP_TRY(hipGetLastError());
+        return F110_OK;
+    }
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     const size_t smem = pure_pursuit_lds_bytes(M);

@@ -233,6 +233,108 @@ __global__ __launch_bounds__(PP_WAVES * 64) void pure_pursuit_kernel(PlanArgs a)
     }
 }
 
+// ------------------------------------------------------------------ one LANE per car behind a grid of candidate lists (round 5)
+// The wave-per-car kernel above prunes 64-segment blocks by their boxes, but it still spends a whole wavefront, a copy of the
+// raceline in LDS and a dozen wave-wide reductions on every car: 66 us for 65 536 cars.  For a raceline that has been
+// PREPARED (f110_pure_pursuit_prepare: once per raceline) the nearest segment is searched among a handful of candidates:
+// a uniform grid over the raceline's surroundings holds, per cell, the ascending list of the segments that can be the
+// nearest one for ANY pose in the cell.  With c the cell's centre, hd its half diagonal and D = min_j dist(c, seg_j): a
+// segment with dist(c, seg) > D + 2 hd lies farther than the nearest one from every point of the cell (|dist(p, s) - dist(c, s)|
+// <= |p - c| <= hd for every segment s), so the list holds dist(c, seg) <= D + 2 hd + 1e-6 (the margin is nine orders of
+// magnitude above the rounding of the distances).  The arg-min itself is the reference's: the same expression per segment
+// (:31-46), strict `<` in ascending index order = np.argmin's first minimum.  A cell with more candidates than the list
+// holds (a pose equally far from a long stretch of the raceline), a pose outside the grid and a NaN pose take every
+// segment, in the same lane: the same results, slower, and rare.  The look-ahead point (:49-129) is searched segment by
+// segment from the nearest one, as the reference does.
+constexpr int PG_CAP = 30;            // candidates a cell's list holds
+constexpr unsigned PG_ALL = 255;      // count value: take every segment
+struct PlanGrid {
+    double x0, y0, inv_cell;          // cell (ix, iy) covers x0 + ix / inv_cell ...
+    int gw, gh;
+    const uint8_t *count;             // [gh * gw]
+    const uint16_t *cand;             // [gh * gw][PG_CAP] ascending segment indices
+    int degenerate;                   // the raceline has a zero-length segment: plan() answers (0, 4.0) for every pose
+};
+
+__global__ __launch_bounds__(256) void pure_pursuit_grid_kernel(PlanArgs a, PlanGrid g)
+{
+    const int car = blockIdx.x * blockDim.x + threadIdx.x;
+    if (car >= a.n) return;
+    const double *__restrict__ wp = a.waypoints;
+    const int M = a.M, nseg = M - 1;
+    const double px = a.state[(size_t)car * 7], py = a.state[(size_t)car * 7 + 1], theta = a.state[(size_t)car * 7 + 4];
+    double steer = 0.0, speed = 4.0; // plan(): lookahead_point is None -> (4.0, 0.0)
+    bool have = false;
+    double lx = 0, ly = 0, lv = 0;
+    if (!g.degenerate) {
+        // nearest_point_on_trajectory (:16-47) over the cell's candidates
+        double best = __builtin_inf(), best_t = 0;
+        int best_i = 0;
+        auto consider = [&](int i) {
+            const double x0 = wp[3 * i], y0 = wp[3 * i + 1];
+            const double dx = wp[3 * i + 3] - x0, dy = wp[3 * i + 4] - y0;
+            const double l2 = dx * dx + dy * dy;
+            double t = ((px - x0) * dx + (py - y0) * dy) / l2;
+            t = t < 0.0 ? 0.0 : t;
+            t = t > 1.0 ? 1.0 : t;
+            const double qx = px - (x0 + t * dx), qy = py - (y0 + t * dy);
+            const double d = sqrt(qx * qx + qy * qy);
+            if (d < best) { best = d; best_i = i; best_t = t; }
+        };
+        const double fx = floor((px - g.x0) * g.inv_cell), fy = floor((py - g.y0) * g.inv_cell);
+        unsigned cnt = PG_ALL;
+        size_t cell = 0;
+        if (fx >= 0.0 && fx < (double)g.gw && fy >= 0.0 && fy < (double)g.gh) { // (false for a NaN pose)
+            cell = (size_t)(int)fy * (size_t)g.gw + (size_t)(int)fx;
+            cnt = g.count[cell];
+        }
+        if (cnt == PG_ALL) for (int i = 0; i < nseg; i++) consider(i);
+        else {
+            const uint16_t *lst = g.cand + cell * PG_CAP;
+            for (unsigned k = 0; k < cnt; k++) consider((int)lst[k]);
+        }
+        if (best < a.lookahead) {
+            // first_point_on_trajectory_intersecting_circle(position, lookahead, wpts, i + t, wrap=True) (:49-129)
+            const double targ = (double)best_i + best_t;
+            const int start_i = (int)targ;
+            const double start_t = fmod(targ, 1.0);
+            int i2 = 0;
+            bool found = false;
+            for (int i = start_i; i < M - 1 && !found; i++) {
+                double t1, t2;
+                if (seg_circle(wp[3 * i], wp[3 * i + 1], wp[3 * i + 3], wp[3 * i + 4], px, py, a.lookahead, t1, t2)) {
+                    const bool h1 = t1 >= 0.0 && t1 <= 1.0, h2 = t2 >= 0.0 && t2 <= 1.0;
+                    if (i == start_i ? ((h1 && t1 >= start_t) || (h2 && t2 >= start_t)) : (h1 || h2)) { found = true; i2 = i; }
+                }
+            }
+            for (int i = -1; i < start_i && !found; i++) {
+                const int i0 = i < 0 ? i + M : i, i1 = (i + 1) % M; // Python's % on a negative index
+                double t1, t2;
+                if (seg_circle(wp[3 * i0], wp[3 * i0 + 1], wp[3 * i1], wp[3 * i1 + 1], px, py, a.lookahead, t1, t2))
+                    if ((t1 >= 0.0 && t1 <= 1.0) || (t2 >= 0.0 && t2 <= 1.0)) { found = true; i2 = i; }
+            }
+            if (found) {
+                const int j = i2 < 0 ? i2 + M : i2; // wpts[i2, :] with Python negative indexing
+                have = true; lx = wp[3 * j]; ly = wp[3 * j + 1]; lv = wp[3 * best_i + 2];
+            }
+        } else if (best < a.max_reacquire) {
+            have = true; lx = wp[3 * best_i]; ly = wp[3 * best_i + 1]; lv = wp[3 * best_i + 2];
+        }
+    }
+    if (have) { // get_actuation (:131-144)
+        const double wy = sin(-theta) * (lx - px) + cos(-theta) * (ly - py);
+        speed = lv;
+        if (fabs(wy) < 1e-6) steer = 0.;
+        else {
+            const double radius = 1 / (2.0 * wy / (a.lookahead * a.lookahead));
+            steer = atan(a.wheelbase / radius);
+        }
+        speed = a.vgain * speed;
+    }
+    a.actions[(size_t)car * 2] = steer;
+    a.actions[(size_t)car * 2 + 1] = speed;
+}
+
 // ------------------------------------------------------------------ many tracks / racelines of any length
 // The kernel above stages ONE raceline in LDS (<= 6 400 points).  The reference loads any CSV
 // (examples/waypoint_follow.py:162) and every F110Env has its own planner and track; a shard that drives K random tracks

@@ -513,9 +513,11 @@ class Engine(object):
     # ------------------------------------------------------------------ planner
     @on_own_device
     def pure_pursuit(self, waypoints, lookahead, vgain, wheelbase=0.17145 + 0.15875, max_reacquire=20.,
-                     state=None, out=None):
+                     state=None, out=None, prepare=True):
         """waypoints: [M,3] (x, y, speed) device tensor; returns actions [B,A,2] (steer, speed)
-        planned from the current state -- feed it straight to step()."""
+        planned from the current state -- feed it straight to step().  prepare: a raceline tensor that is planned on
+        a second time (same storage, unchanged since: torch's version counter) is prepared once (f110_pure_pursuit_prepare:
+        a grid of candidate segments, ~0.1 s on the host) and from then on planned with one lane per car."""
         st = self.t['state'] if state is None else self._dev64(state, (-1, 7))
         n = st.numel() // 7
         if out is None:
@@ -523,6 +525,16 @@ class Engine(object):
         if not (torch.is_tensor(waypoints) and waypoints.device == self.device and waypoints.dtype == torch.float64
                 and waypoints.is_contiguous()):
             waypoints = self._dev64(waypoints, (-1, 3))
+        elif prepare and not self._in_capture and 2 <= waypoints.shape[0] <= 65535:
+            key = (waypoints.data_ptr(), waypoints._version, waypoints.shape[0])
+            if getattr(self, '_plan_seen', None) == key and getattr(self, '_plan_key', None) != key:
+                _lib.check(self.lib.f110_pure_pursuit_prepare(self._h, _ptr(waypoints), waypoints.shape[0], 0.0, 0.0, self._stream()))
+                self._plan_key = key
+            elif getattr(self, '_plan_key', None) is not None and self._plan_key != key and self._plan_key[0] == key[0]:
+                # same storage, new values: the prepared grid is stale -- forget it (prepared again on the next call)
+                _lib.check(self.lib.f110_pure_pursuit_prepare(self._h, _ptr(waypoints), waypoints.shape[0], 0.0, 0.0, self._stream()))
+                self._plan_key = key
+            self._plan_seen = key
         _lib.check(self.lib.f110_pure_pursuit(self._h, _ptr(waypoints), waypoints.shape[0], float(lookahead),
                                               float(vgain), float(wheelbase), float(max_reacquire), _ptr(st), n,
                                               _ptr(out), self._stream()))

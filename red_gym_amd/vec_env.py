@@ -33,7 +33,11 @@ class F110VecEnv(object):
                  noise_source='device', **_ignored):
         """The reference's constructor keywords (f110_env.py:100-157) plus the batch: `params` and `seed` may each be ONE
         value for every env, or a sequence of num_envs values -- env e is then what `F110Env(params=params[e],
-        seed=seed[e])` would be (equal values share a slot on the device; at most 64 distinct seeds)."""
+        seed=seed[e])` would be (equal values share a slot on the device; more than 64 distinct seeds switch the device noise to
+        one generator per env, `noise_source='per_env'`).  The scan's beam tables and side distances are built ONCE, from env 0's
+        params -- what reference envs created in one process share through RaceCar's class-level statics (base_classes.py:116-156),
+        not what independently started processes would have: an env whose `width` / `lf` / `lr` differ still uses env 0's side
+        distances for its iTTC test."""
         self.num_envs, self.num_agents = int(num_envs), int(num_agents)
         self.map_name, self.map_ext = map, map_ext
         self.map_path = resolve_map_path(map)
@@ -213,12 +217,13 @@ class F110VecEnv(object):
         self.eng.host_steps_bound += 1
         return self._result()
 
-    def pure_pursuit(self, waypoints, lookahead, vgain, wheelbase=0.17145 + 0.15875):
+    def pure_pursuit(self, waypoints, lookahead, vgain, wheelbase=0.17145 + 0.15875, prepare=True):
         """Batched pure-pursuit actions for the current poses (examples/waypoint_follow.py planner
-        on the GPU); waypoints [M,3] = (x, y, speed)."""
+        on the GPU); waypoints [M,3] = (x, y, speed).  A device tensor that is planned on repeatedly is prepared once
+        (Engine.pure_pursuit) and then costs one lane per car."""
         if not torch.is_tensor(waypoints) or waypoints.device != self.device:
             waypoints = torch.as_tensor(np.ascontiguousarray(waypoints, dtype=np.float64), device=self.device)
-        return self.eng.pure_pursuit(waypoints, lookahead, vgain, wheelbase)
+        return self.eng.pure_pursuit(waypoints, lookahead, vgain, wheelbase, prepare=prepare)
 
     def raceline_slots(self, waypoint_sets, assign):
         """Packs K racelines [M_k,3] = (x, y, speed) and the raceline of every env (int array [num_envs], e.g. the map

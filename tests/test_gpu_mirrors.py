@@ -247,6 +247,70 @@ def test_hip_pure_pursuit_reproduces_reference_recorded_actions(golden, assets):
         assert np.abs(act[:, 0] - g['actions'][:, a, 0]).max() < 1e-9, a
 
 
+def test_hip_pure_pursuit_prepared_raceline_is_the_same_planner(assets, golden):
+    """f110_pure_pursuit_prepare: the grid of candidate lists must not change a single bit of what the planner answers.
+    200 000 poses -- on the raceline, scattered around it (every cell of the grid several times), far outside the grid, NaN --
+    through the prepared (one lane per car) and the unprepared (one wavefront per car) kernel: actions `==`.  Also the golden
+    closed loops of the reference's planner (g8), a raceline whose centre of curvature overflows a cell's list (a circle:
+    every segment is equally near its centre), a degenerate raceline, and a 2-point raceline."""
+    import ctypes as C
+    import torch
+    from red_gym_amd import F110VecEnv, workload
+    from red_gym_amd.engine import _lib, _ptr
+    lib = _lib.load()
+    dev = torch.device('cuda', 0)
+    env = F110VecEnv(4, map=workload.EXAMPLE_MAP, num_agents=1, autoreset=False)   # (a handle to keep the grid in)
+    h = env.eng._h
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+    def plan(w, poses, prepared, tlad=0.82461887897713965, vgain=1.375):
+        st = np.zeros((len(poses), 7)); st[:, [0, 1, 4]] = poses
+        st = torch.as_tensor(st, device=dev)
+        out = torch.empty((len(poses), 2), dtype=torch.float64, device=dev)
+        _lib.check(lib.f110_pure_pursuit(h if prepared else None, _ptr(w), w.shape[0], tlad, vgain, 0.17145 + 0.15875, 20.0, _ptr(st), len(poses),
+                                         _ptr(out), stream))
+        return out.cpu().numpy()
+
+    rng = np.random.default_rng(11)
+    wp = _example_raceline(assets)
+    circle = np.stack([5 * np.cos(np.linspace(0, 2 * np.pi, 400, endpoint=False)), 5 * np.sin(np.linspace(0, 2 * np.pi, 400, endpoint=False)),
+                       np.full(400, 3.0)], axis=1)
+    bad = np.concatenate([wp[:200], wp[199:200], wp[200:]])
+    two = np.array([[0.0, 0.0, 2.0], [3.0, 1.0, 2.5]])
+    for name, line in (('example', wp), ('circle', circle), ('degenerate', bad), ('two points', two)):
+        w = torch.as_tensor(np.ascontiguousarray(line), device=dev)
+        _lib.check(lib.f110_pure_pursuit_prepare(h, _ptr(w), w.shape[0], 0.0, 0.0, stream))
+        n = 200000 if name == 'example' else 20000
+        k = rng.integers(0, len(line), n)
+        poses = np.stack([line[k, 0], line[k, 1], rng.uniform(-np.pi, np.pi, n)], axis=1)
+        poses[:, :2] += rng.normal(0, 1.0, (n, 2)) * rng.choice([0.0, 0.05, 0.4, 1.5, 4.0], (n, 1))
+        lo, hi = line[:, :2].min(0) - 3.5, line[:, :2].max(0) + 3.5
+        m = n // 10
+        poses[:m, :2] = rng.uniform(lo, hi, (m, 2))                       # uniformly over (and just past) the grid
+        poses[m:m + 50, :2] = rng.uniform(-500, 500, (50, 2))             # far outside
+        poses[m + 50:m + 54, 0] = np.nan                                  # NaN poses
+        poses[m + 54:m + 58, :2] = 0.0                                    # the circle's centre: every segment equally near
+        a0, a1 = plan(w, poses, False), plan(w, poses, True)
+        assert np.array_equal(a0, a1, equal_nan=True), (name, int((a0 != a1).sum()))
+        if name == 'degenerate':
+            assert (a1 == [0.0, 4.0]).all()
+    # the reference's own recorded actions through the prepared kernel
+    w = torch.as_tensor(np.ascontiguousarray(wp), device=dev)
+    _lib.check(lib.f110_pure_pursuit_prepare(h, _ptr(w), w.shape[0], 0.0, 0.0, stream))
+    g = golden('g8_env.npz')
+    poses = np.concatenate([g['reset_obs'][None, :3], np.stack([g['x'], g['y'], g['theta']], axis=1)[:-1]])
+    act = plan(w, poses, True)
+    assert np.array_equal(act[:, 1], g['actions'][:, 1]) and np.abs(act[:, 0] - g['actions'][:, 0]).max() < 1e-9
+    # Engine.pure_pursuit prepares a raceline tensor on its second use and plans the same
+    wt = torch.as_tensor(np.ascontiguousarray(wp), device=dev)
+    env.reset(workload.spawn_poses(4, 1))
+    b0 = env.pure_pursuit(wt, 0.8, 1.2).clone()
+    b1 = env.pure_pursuit(wt, 0.8, 1.2).clone()
+    b2 = env.pure_pursuit(wt, 0.8, 1.2).clone()
+    assert env.eng._plan_key is not None and torch.equal(b0, b1) and torch.equal(b1, b2)
+    env.close()
+
+
 def test_hip_pure_pursuit_degenerate_raceline(assets):
     """Two equal consecutive waypoints: the reference's nearest-point search divides 0 by 0 on that segment, np.argmin
     returns it, and the NaN distance makes plan() answer (4.0, 0.0) for every pose (waypoint_follow.py:16-47, :189-212).

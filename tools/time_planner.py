@@ -9,12 +9,14 @@ env = F110VecEnv(B, map=workload.EXAMPLE_MAP, num_agents=1, autoreset=True)
 env.reset(torch.as_tensor(workload.spawn_poses(B, 1), device=env.device))
 rl = workload.load_waypoints(workload.RACELINE)
 wp = torch.as_tensor(np.ascontiguousarray(rl[:, [1, 2, 5]]), device=env.device)
-for _ in range(20):
-    env.step(env.pure_pursuit(wp, 0.82461887897713965, 1.375))
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-torch.cuda.synchronize(); e0.record()
-for _ in range(100):
-    a = env.pure_pursuit(wp, 0.82461887897713965, 1.375)
-e1.record(); torch.cuda.synchronize()
-print('%s: pure_pursuit_kernel %d cars, %d waypoints: %.1f us per call' % (os.path.basename(os.environ.get('F110_LIB', 'default')), B, wp.shape[0], e0.elapsed_time(e1) * 10))
+for prepare in (False, True):   # one wavefront per car over 64-segment blocks / one lane per car over the prepared grid
+    for _ in range(20):
+        env.step(env.pure_pursuit(wp, 0.82461887897713965, 1.375, prepare=prepare))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(100):
+        a = env.pure_pursuit(wp, 0.82461887897713965, 1.375, prepare=prepare)
+    e1.record(); torch.cuda.synchronize()
+    print('%s: pure pursuit, %d cars, %d waypoints, %s: %.1f us per call' % (os.path.basename(os.environ.get('F110_LIB', 'default')), B, wp.shape[0],
+          'prepared raceline (grid kernel)' if env.eng.__dict__.get('_plan_key') else 'unprepared (wave per car)', e0.elapsed_time(e1) * 10), flush=True)
 env.close()
