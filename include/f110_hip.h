@@ -28,7 +28,7 @@
  *     an ordinary access to the caller's own memory between steps (F110VecEnv.state_dict / load_state_dict).
  *   - tuning knobs read from the environment at first use (sweeps only; the defaults are the measured optimum):
  *     F110_WPC = 1|2|4|8 wavefronts per car in the scan kernel; F110_STAGES = "cars:log2waves,..." wave -> car
- *     stage list of a scan launch ("*" = the remaining cars), see launch_scan in csrc/f110_abi.hip.
+ *     stage list of a scan launch ("*" = the remaining cars), see launch_scan in csrc/f110_step.hip.
  *   - all arithmetic that decides an index, a collision or a lap toggle is
  *     IEEE fp64 in the reference's operation order (no FMA contraction).
  */

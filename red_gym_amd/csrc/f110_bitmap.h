@@ -253,7 +253,8 @@ __device__ inline int2 bm_point(const BitmapArgs &a, int img, int k, int cx, int
 }
 
 // function-level view of the point stage (f110_bitmap_points): out [n, T, 2] int32 (x, y)
-__global__ __launch_bounds__(256) void bitmap_points_kernel(BitmapArgs a, int *out)
+#if defined(F110_UNIT_CONSUMERS)
+static __global__ __launch_bounds__(256) void bitmap_points_kernel(BitmapArgs a, int *out)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)a.n * a.T) return;
@@ -262,8 +263,10 @@ __global__ __launch_bounds__(256) void bitmap_points_kernel(BitmapArgs a, int *o
     out[2 * i] = p.x;
     out[2 * i + 1] = p.y;
 }
+#endif
 
-__global__ __launch_bounds__(BM_THREADS) void bitmap_kernel(BitmapArgs a)
+#if defined(F110_UNIT_CONSUMERS)
+static __global__ __launch_bounds__(BM_THREADS) void bitmap_kernel(BitmapArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     __shared__ int s_wave[BM_THREADS / 64];
@@ -512,6 +515,7 @@ __global__ __launch_bounds__(BM_THREADS) void bitmap_kernel(BitmapArgs a)
         }
     }
 }
+#endif
 
 // ---- f1tenth_gym/examples/lidar.py:212-244: point-occupancy grid (one workgroup per scan)
 struct OccArgs {
@@ -522,7 +526,8 @@ struct OccArgs {
     unsigned char *out;        // [n, grid, grid]
 };
 
-__global__ __launch_bounds__(BM_THREADS) void occupancy_kernel(OccArgs a)
+#if defined(F110_UNIT_CONSUMERS)
+static __global__ __launch_bounds__(BM_THREADS) void occupancy_kernel(OccArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     unsigned *bits = reinterpret_cast<unsigned *>(s_raw); // grid*grid bits
@@ -556,5 +561,6 @@ __global__ __launch_bounds__(BM_THREADS) void occupancy_kernel(OccArgs a)
         for (int p = tid; p < G * G; p += BM_THREADS) dst[p] = (unsigned char)((bits[p >> 5] >> (p & 31)) & 1u);
     }
 }
+#endif
 
 } // namespace f110

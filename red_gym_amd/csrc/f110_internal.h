@@ -1,0 +1,173 @@
+// f110_internal.h -- what the translation units of libf110_hip.so share: the handle, the error plumbing and the few helpers
+// that cross a unit's border.  The kernels live in headers as `static __global__` functions: a unit instantiates the ones it
+// launches.  Units (red_gym_amd/build.py compiles them in parallel and links them into the one library):
+//   f110_handle.hip     handle life cycle, host tables, vehicle parameters, buffers, device error word, host EDT
+//   f110_maps.hip       map installation (host table / occupancy mask -> cell codes, LUTs), device EDT, track mask
+//   f110_noise_abi.hip  lidar noise: slots, ring, generators, per-env mode
+//   f110_step.hip       launch policy of the scan, the step, hipGraphs, measurement aid, function-level entry points
+//   f110_consumers.hip  the callers either side of the step: pure-pursuit planner, scan -> bitmap, occupancy grid
+#pragma once
+#include "../../include/f110_hip.h"
+#include "f110_kernels.h"
+#include "f110_planner.h"
+#include "f110_bitmap.h"
+#include "f110_mapgen.h"
+
+#include <hip/hip_ext.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <utility>
+#include <vector>
+
+using namespace f110;
+
+int fail(int code, const char *fmt, ...);
+
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(F110_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+// Makes `dev` the calling thread's current device for the scope of one library call and restores the caller's own
+// afterwards: a process that drives several GPUs (or several handles on different GPUs) keeps ITS current device across
+// every call.  f110_step / f110_reset and the function-level entry points do not switch -- they launch on the caller's
+// stream, which belongs to the caller's current device -- they check (check_device) and refuse a mismatch.
+struct DeviceScope {
+    int prev = -1;
+    bool switched = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceScope(int dev)
+    {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != dev) {
+            err = hipSetDevice(dev);
+            switched = err == hipSuccess;
+        }
+    }
+    ~DeviceScope() { if (switched) (void)hipSetDevice(prev); }
+    DeviceScope(const DeviceScope &) = delete;
+    DeviceScope &operator=(const DeviceScope &) = delete;
+};
+#define ON_DEVICE(dev)            \
+    DeviceScope dev_scope_(dev);  \
+    HIP_TRY(dev_scope_.err)
+
+
+struct f110_handle {
+    f110_config cfg;
+    // Vehicle parameters, [slots][1 + A]: per params slot (the `params` one reference env was constructed with) entry 0 =
+    // Simulator.params (GJK vertices, base_classes.py:542), entry 1 + i = RaceCar.params of agent i
+    std::vector<Params> h_params;
+    int param_slots = 1;
+    Params *d_params = nullptr;
+    int d_params_slots = 0;           // slots the device allocation holds
+    int32_t *d_env_params = nullptr;  // dev [B] params slot of every env; passed to the kernels only when `multi_params`
+    bool multi_params = false;
+    OppPair *d_opp_pairs = nullptr;   // [N, A-1] opponent ray-cast scratch (never allocated in f110_step)
+    uint8_t *d_was_pending = nullptr; // [B] pending_reset as the step's first kernel found it
+    bool has_map = false, bound = false;
+    // Bumped whenever a later f110_step would enqueue different kernels or by-value arguments than an earlier one
+    // (a table re-allocated, another scan instantiation selected, buffers re-bound): f110_launch_epoch.
+    int64_t epoch = 0;
+    std::string stages;               // f110_set_scan_stages override ("" = F110_STAGES or the built-in choice)
+    f110_buffers bufs;
+    // device tables owned by the handle
+    double *d_scan_angles = nullptr, *d_beam_cosines = nullptr, *d_side = nullptr;
+    uint16_t *d_chunk0 = nullptr;
+    double2 *d_cs = nullptr;          // interleaved {cos, sin} LUT (repeated, see upload_cs)
+    int cs_len = 0;
+    double2 *d_beam_cs = nullptr;     // {cos, sin}(scan_angles) for the opponent ray cast
+    std::vector<double> h_sines, h_cosines;
+    // Lidar noise (f110_noise.h): [noise_slots][cap][nb] noise rows, rows lo .. hi-1 present; the kernels
+    // find it through d_noise_desc, whose address never changes
+    double *d_noise = nullptr;        // [noise_slots][noise_cap][num_beams] noise rows (a ring per slot)
+    double side_max = 0.0;            // largest finite side distance (the scan's pre-test for iTTC candidates)
+    long long noise_cap = 0, noise_lo = 0, noise_hi = 0; // cap: rows per slot (a power of two); noise off: cap 1, hi = "infinity"
+    int noise_slots = 1;
+    bool noise_on = false;
+    NoiseDesc *d_noise_desc = nullptr;
+    struct NoiseSlot {
+        int kind = 0;                 // 0 unset (zeros), 1 host-fed table, 2 generator
+        std::vector<double> rows;     // host-fed: [T, nb]
+        long long T = 0;              // rows the slot can serve: host-fed = table length, generator = rows produced
+        NoiseGen seed;                // generator: the stream at row 0
+    };
+    NoiseSlot nslots[F110_MAX_NOISE_SLOTS];
+    NoiseGen *d_noise_gen = nullptr;  // [F110_MAX_NOISE_SLOTS] device generator states
+    int32_t *d_env_noise = nullptr;   // dev [B] noise slot of every env; passed only when `multi_noise`
+    bool multi_noise = false;
+    hipStream_t noise_stream = nullptr; // the generator runs here, beside the caller's stream (f110_noise_prefetch)
+    hipEvent_t noise_ev = nullptr;
+    long long noise_pending_hi = 0;   // rows a prefetch in flight on noise_stream will have produced (0: none in flight)
+    // Ordering of the side stream behind the caller's: recorded on the caller's stream whenever the floor is raised (the steps
+    // enqueued so far may still read the rows below it, whose ring places the next prefetch recycles) and whenever a generator
+    // kernel is enqueued there (it reads and writes the same generator states); the next prefetch waits for it.
+    hipEvent_t order_ev = nullptr;
+    bool order_ev_set = false;
+    // prepared raceline of f110_pure_pursuit (f110_pure_pursuit_prepare): grid of candidate lists (f110_planner.h PlanGrid)
+    const double *plan_wp = nullptr; int plan_M = 0; bool plan_ok = false;
+    PlanGrid plan_grid;
+    uint8_t *d_plan_count = nullptr; uint16_t *d_plan_cand = nullptr;
+    u128 *d_pcg_tab = nullptr;        // [2][65] powers and partial sums of the LCG multiplier (f110_noise.h NoiseGenArgs::pcg_tab)
+    // per-env noise (f110_set_noise_per_env): every env its own generator and ONE row, produced in front of every step's scan
+    bool per_env_noise = false;
+    NoiseGen *d_env_gen = nullptr, *d_env_seed = nullptr;   // [num_envs]
+    double *d_env_rows = nullptr;                           // [num_envs][num_beams]
+    int32_t *d_env_ident = nullptr;                         // [num_envs] env -> slot = env
+    NoiseMark *d_marks = nullptr;     // [noise_slots][marks_cap] generator state at every 64th row (f110_noise.h NoiseMark)
+    long long marks_cap = 0;
+    int marks_slots = 0;
+    struct Retired { void *ptr; hipEvent_t ev; };
+    std::vector<Retired> retired;     // old noise tables, freed once the work that may read them has drained
+    uint32_t *d_err = nullptr;        // device error word (f110_device_errors)
+    std::vector<double> h_side;       // side distances (host copy of d_side)
+    // Maps.  Slot 0 is "the" map of the reference's API; further slots let blocks of envs of one shard run on
+    // different maps (one handle standing in for many F110Env instances with their own map each).
+    struct MapSlot {
+        uint16_t *d_cells = nullptr, *d_cells_far = nullptr;
+        double *d_lut = nullptr, *d_lut_lds = nullptr, *d_dt = nullptr;
+        MapDev dev;                   // host copy of d_maps[slot]
+        bool used = false, ident = false, pow2 = false;
+    };
+    MapSlot slots[F110_MAX_MAPS];
+    MapDev *d_maps = nullptr;         // dev [F110_MAX_MAPS] descriptors read by scan_kernel
+    int32_t *d_env_map = nullptr;     // dev [B] slot of every env; only passed to the kernel when `multi`
+    std::vector<int32_t> h_env_map;   // host copy (all 0 until f110_assign_maps)
+    bool multi = false;
+    bool ident = false, pow2 = false; // AND over the used slots: selects the scan_kernel instantiation
+    double theta_inc = 0;
+    // measurement aid (f110_profile_begin/end)
+    std::vector<hipEvent_t> prof_ev; // pairs: [2*i] before, [2*i+1] after the scan launch
+    int prof_n = 0, prof_every = 1, prof_seq = 0; // events ride on every prof_every-th step's scan launch (the middle one of
+                                                  // each run of prof_every steps: on a clock ramp the samples' mean is then the steps' mean)
+    bool prof_on = false;
+};
+
+struct DevTemp { // frees its device scratch on every exit path
+    std::vector<void *> ptrs;
+    ~DevTemp() { for (void *p : ptrs) if (p) (void)hipFree(p); }
+    template <typename T> hipError_t alloc(T **out, size_t n)
+    {
+        void *p = nullptr;
+        const hipError_t e = hipMalloc(&p, n * sizeof(T));
+        if (e == hipSuccess) ptrs.push_back(p);
+        *out = static_cast<T *>(p);
+        return e;
+    }
+};
+
+// helpers defined in f110_handle.hip / f110_noise_abi.hip and used elsewhere
+int check_current_device(int dev, const char *who);
+int check_device(const f110_handle *h, const char *who);
+int upload(double **dst, const double *src, size_t n);
+int noise_init(f110_handle *h);

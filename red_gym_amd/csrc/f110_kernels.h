@@ -1069,7 +1069,9 @@ __device__ inline void opp_setup_body(const OppArgs &a, int t)
     out.n_iv = n_iv; out.total = total;
 }
 
-__global__ __launch_bounds__(128) void opp_setup_kernel(OppArgs a) { opp_setup_body(a, blockIdx.x * blockDim.x + threadIdx.x); }
+#if defined(F110_UNIT_STEP)
+static __global__ __launch_bounds__(128) void opp_setup_kernel(OppArgs a) { opp_setup_body(a, blockIdx.x * blockDim.x + threadIdx.x); }
+#endif
 
 #ifndef F110_OPP_GROUP
 #define F110_OPP_GROUP 64
@@ -1077,7 +1079,8 @@ __global__ __launch_bounds__(128) void opp_setup_kernel(OppArgs a) { opp_setup_b
 constexpr int OPP_GROUP = F110_OPP_GROUP; // lanes per car in opp_apply_kernel (measured at 32 768 cars: 8 lanes 52 us, 16: 33, 32: 27, 64: 23)
 constexpr int OPP_GROUP_MAX = 256; // a pair with more beams than this is walked by the whole wave, not by its group
 
-__global__ __launch_bounds__(256, 8) void opp_apply_kernel(OppArgs a)
+#if defined(F110_UNIT_STEP)
+static __global__ __launch_bounds__(256, 8) void opp_apply_kernel(OppArgs a)
 {
     __shared__ OppPair s_pair[256 / OPP_GROUP]; // one per group
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1127,6 +1130,7 @@ __global__ __launch_bounds__(256, 8) void opp_apply_kernel(OppArgs a)
         __builtin_amdgcn_wave_barrier(); // the LDS copies are overwritten by the next opponent's
     }
 }
+#endif
 
 // ------------------------------------------------------------------ dynamics (lane per car)
 struct DynArgs {
@@ -1160,7 +1164,8 @@ struct DynArgs {
 // slow car into most wavefronts).  The block therefore deals its cars out so that the slow ones (and the idle lanes)
 // share the LAST wavefronts: lane l works on car s_perm[l], the others' waves skip the kinematic code altogether.
 // Which lane integrates a car does not change a bit of its result.
-__global__ __launch_bounds__(256) void dynamics_kernel(DynArgs a)
+#if defined(F110_UNIT_STEP)
+static __global__ __launch_bounds__(256) void dynamics_kernel(DynArgs a)
 {
     __shared__ int s_perm[256];
     __shared__ int s_cnt[2][4]; // per wave: fast cars, slow cars
@@ -1241,6 +1246,7 @@ __global__ __launch_bounds__(256) void dynamics_kernel(DynArgs a)
         a.pose_snap[(size_t)car * 3 + 2] = st[4];
     }
 }
+#endif
 
 // ------------------------------------------------------------------ env bookkeeping (lane per env)
 struct EnvArgs {
@@ -1338,7 +1344,8 @@ struct CheckDoneArgs {
     uint8_t *checkpoint_done;   // [n,A] or NULL
 };
 
-__global__ __launch_bounds__(128) void check_done_kernel(CheckDoneArgs a)
+#if defined(F110_UNIT_STEP)
+static __global__ __launch_bounds__(128) void check_done_kernel(CheckDoneArgs a)
 {
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= a.n_envs) return;
@@ -1349,6 +1356,7 @@ __global__ __launch_bounds__(128) void check_done_kernel(CheckDoneArgs a)
                                          a.lap_times + c0, a.checkpoint_done ? a.checkpoint_done + c0 : nullptr);
     a.done[env] = ((a.collisions[c0 + a.ego_idx] != 0) || all_done) ? 1 : 0; // :242
 }
+#endif
 
 // ONE: the env has one agent (no pair to test: the GJK code is not even compiled in, the kernel is a third of the size)
 template <bool ONE>
@@ -1414,11 +1422,13 @@ struct PostScanArgs {
     int env_blocks;
 };
 
-__global__ __launch_bounds__(128) void post_scan_kernel(PostScanArgs a)
+#if defined(F110_UNIT_STEP)
+static __global__ __launch_bounds__(128) void post_scan_kernel(PostScanArgs a)
 {
     if ((int)blockIdx.x < a.env_blocks) env_body<false>(a.e, blockIdx.x * blockDim.x + threadIdx.x);
     else opp_setup_body(a.o, (blockIdx.x - a.env_blocks) * blockDim.x + threadIdx.x);
 }
+#endif
 
 // ------------------------------------------------------------------ one env's observation in one buffer
 // The single-env facade (red_gym_amd.F110Env = the reference's Gym API on a batch of one) returns NumPy / Python objects
@@ -1432,7 +1442,8 @@ struct PackArgs {
     double *out;
 };
 
-__global__ __launch_bounds__(256) void pack_env_kernel(PackArgs a)
+#if defined(F110_UNIT_STEP)
+static __global__ __launch_bounds__(256) void pack_env_kernel(PackArgs a)
 {
     const int A = a.agents, c0 = a.env * A;
     const int n_small = 11 * A + 2, n = n_small + A * a.nb;
@@ -1452,10 +1463,12 @@ __global__ __launch_bounds__(256) void pack_env_kernel(PackArgs a)
         a.out[i] = v;
     }
 }
+#endif
 
 // ------------------------------------------------------------------ function-level kernels
 // dynamic_models.py:91-121 / :124-176 right-hand sides (the reference's KAT surface)
-__global__ void rhs_kernel(const double *x, const double *u, int n, int kinematic, const Params *params, double *f)
+#if defined(F110_UNIT_STEP)
+static __global__ void rhs_kernel(const double *x, const double *u, int n, int kinematic, const Params *params, double *f)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1474,8 +1487,10 @@ __global__ void rhs_kernel(const double *x, const double *u, int n, int kinemati
     }
     for (int k = 0; k < 7; k++) f[(size_t)i * 7 + k] = fs[k];
 }
+#endif
 
-__global__ void vertices_kernel(const double *poses, int n, double L, double W, double *out)
+#if defined(F110_UNIT_STEP)
+static __global__ void vertices_kernel(const double *poses, int n, double L, double W, double *out)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1483,8 +1498,10 @@ __global__ void vertices_kernel(const double *poses, int n, double L, double W, 
     get_vertices(poses[3 * i], poses[3 * i + 1], poses[3 * i + 2], L, W, v);
     for (int k = 0; k < 4; k++) { out[(size_t)i * 8 + 2 * k] = v[k][0]; out[(size_t)i * 8 + 2 * k + 1] = v[k][1]; }
 }
+#endif
 
-__global__ void gjk_pairs_kernel(const double *va, const double *vb, int n, uint8_t *hit)
+#if defined(F110_UNIT_STEP)
+static __global__ void gjk_pairs_kernel(const double *va, const double *vb, int n, uint8_t *hit)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1495,8 +1512,10 @@ __global__ void gjk_pairs_kernel(const double *va, const double *vb, int n, uint
     }
     hit[i] = gjk_collision(a, b) ? 1 : 0;
 }
+#endif
 
-__global__ void collision_multiple_kernel(const double *verts, int n, int A, uint8_t *col, int32_t *cidx)
+#if defined(F110_UNIT_STEP)
+static __global__ void collision_multiple_kernel(const double *verts, int n, int A, uint8_t *col, int32_t *cidx)
 {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n) return;
@@ -1514,9 +1533,11 @@ __global__ void collision_multiple_kernel(const double *verts, int n, int A, uin
         }
     }
 }
+#endif
 
 // check_ttc_jit (laser_models.py:189-217): wave per scan
-__global__ void ttc_kernel(const double *scans, const double *vel, int n, int nb, const double *beam_cosines,
+#if defined(F110_UNIT_STEP)
+static __global__ void ttc_kernel(const double *scans, const double *vel, int n, int nb, const double *beam_cosines,
                            const double *side_distances, double thresh, uint8_t *hit)
 {
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -1533,9 +1554,11 @@ __global__ void ttc_kernel(const double *scans, const double *vel, int n, int nb
     const bool any = __ballot(h) != 0ull;
     if (lane == 0) hit[row] = any ? 1 : 0;
 }
+#endif
 
 // ray_cast (laser_models.py:319-346): wave per (ego, opponent quad)
-__global__ void ray_cast_kernel(const double *ego, const double *verts, int n, int nb, const double *scan_angles,
+#if defined(F110_UNIT_STEP)
+static __global__ void ray_cast_kernel(const double *ego, const double *verts, int n, int nb, const double *scan_angles,
                                 const double2 *beam_cs,
                                 double *scans, int32_t *span)
 {
@@ -1546,5 +1569,6 @@ __global__ void ray_cast_kernel(const double *ego, const double *verts, int n, i
     ray_cast_wave(ego[3 * row], ego[3 * row + 1], ego[3 * row + 2], v, scan_angles, beam_cs, nb, lane,
                   scans + (size_t)row * nb, nullptr, span ? span + 2 * row : nullptr);
 }
+#endif
 
 } // namespace f110

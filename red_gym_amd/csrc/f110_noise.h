@@ -156,7 +156,7 @@ struct NoiseGenArgs {
     int redo;
     long long chunk0;
     // powers and partial sums of the LCG multiplier: pcg_tab[j] = M^j, pcg_tab[65 + j] = 1 + M + ... + M^(j-1), j = 0 .. 64
-    // (f110_abi.hip computes them once): lane j's start state and the 64-step jump are two multiply-adds instead of loops
+    // (f110_noise_abi.hip computes them once): lane j's start state and the 64-step jump are two multiply-adds instead of loops
     const u128 *pcg_tab;
     // PER-ENV mode (f110_set_noise_per_env: every env its own seed, no limit on their number): slot = env, the table holds ONE
     // row per env (cap = 1), and every step produces the row the env's scan is about to add -- row `pend ? 0 : env_row[slot *
@@ -179,7 +179,8 @@ struct NoiseGenArgs {
 // into the next window if need be: `skip`), everything else is.  The accepted candidates are numbered by a prefix count and
 // stored as consecutive beams.  The window then advances by exactly 64 positions (one 128-bit multiply-add per lane), so
 // there is no re-basing shuffle and the only state carried from window to window is (skip, beams produced).
-__global__ __launch_bounds__(256) void noise_rows_kernel(NoiseGenArgs a)
+#if defined(F110_UNIT_NOISE)
+static __global__ __launch_bounds__(256) void noise_rows_kernel(NoiseGenArgs a)
 {
     __shared__ unsigned long long s_ki[256];
     __shared__ double s_wi[256], s_fi[256];
@@ -307,9 +308,11 @@ __global__ __launch_bounds__(256) void noise_rows_kernel(NoiseGenArgs a)
         T = A * T + C;
     }
 }
+#endif
 
 // host-fed slot: plain fp64 rows [T, nb] (device staging copy; NULL: zeros) -> rows 0 .. T-1 of the slot's ring
-__global__ void noise_fill_kernel(const double *rows, long long T, int nb, double *base, int slot, long long cap, long long mask)
+#if defined(F110_UNIT_NOISE)
+static __global__ void noise_fill_kernel(const double *rows, long long T, int nb, double *base, int slot, long long cap, long long mask)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= T * nb) return;
@@ -317,9 +320,11 @@ __global__ void noise_fill_kernel(const double *rows, long long T, int nb, doubl
     const int b = (int)(i - r * nb);
     base[((size_t)slot * (size_t)cap + (size_t)(r & mask)) * (size_t)nb + b] = rows ? rows[i] : 0.0;
 }
+#endif
 
 // growth: rows lo .. hi-1 of every slot move to their places in a larger ring
-__global__ void noise_move_kernel(const double *src, long long scap, long long smask, double *dst, long long dcap,
+#if defined(F110_UNIT_NOISE)
+static __global__ void noise_move_kernel(const double *src, long long scap, long long smask, double *dst, long long dcap,
                                   long long dmask, int slots, long long lo, long long hi, int nb)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -331,5 +336,6 @@ __global__ void noise_move_kernel(const double *src, long long scap, long long s
     const int b = (int)(k % nb);
     dst[((size_t)s * (size_t)dcap + (size_t)(r & dmask)) * (size_t)nb + b] = src[((size_t)s * (size_t)scap + (size_t)(r & smask)) * (size_t)nb + b];
 }
+#endif
 
 } // namespace f110

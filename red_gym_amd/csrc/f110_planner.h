@@ -81,7 +81,8 @@ __host__ __device__ inline size_t pure_pursuit_lds_bytes(int M)
     return ((size_t)M * 3 + (size_t)nblk * 4) * sizeof(double);
 }
 
-__global__ __launch_bounds__(PP_WAVES * 64) void pure_pursuit_kernel(PlanArgs a)
+#if defined(F110_UNIT_CONSUMERS)
+static __global__ __launch_bounds__(PP_WAVES * 64) void pure_pursuit_kernel(PlanArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double s_wp[]; // [M,3] waypoints, then [nblk,4] block boxes
     const int M = a.M, nseg = M - 1, nblk = (nseg + 63) >> 6;
@@ -232,6 +233,7 @@ __global__ __launch_bounds__(PP_WAVES * 64) void pure_pursuit_kernel(PlanArgs a)
         }
     }
 }
+#endif
 
 // ------------------------------------------------------------------ one LANE per car behind a grid of candidate lists (round 5)
 // The wave-per-car kernel above prunes 64-segment blocks by their boxes, but it still spends a whole wavefront, a copy of the
@@ -256,7 +258,8 @@ struct PlanGrid {
     int degenerate;                   // the raceline has a zero-length segment: plan() answers (0, 4.0) for every pose
 };
 
-__global__ __launch_bounds__(256) void pure_pursuit_grid_kernel(PlanArgs a, PlanGrid g)
+#if defined(F110_UNIT_CONSUMERS)
+static __global__ __launch_bounds__(256) void pure_pursuit_grid_kernel(PlanArgs a, PlanGrid g)
 {
     const int car = blockIdx.x * blockDim.x + threadIdx.x;
     if (car >= a.n) return;
@@ -334,6 +337,7 @@ __global__ __launch_bounds__(256) void pure_pursuit_grid_kernel(PlanArgs a, Plan
     a.actions[(size_t)car * 2] = steer;
     a.actions[(size_t)car * 2 + 1] = speed;
 }
+#endif
 
 // ------------------------------------------------------------------ many tracks / racelines of any length
 // The kernel above stages ONE raceline in LDS (<= 6 400 points).  The reference loads any CSV
@@ -353,7 +357,8 @@ struct TrackSet {
 __device__ inline size_t track_box_row(const TrackSet &t, int k) { return (size_t)(t.offsets[k] >> 6) + (size_t)k; }
 
 // one wave per (raceline, 64-segment block): grid (ceil(max_blocks / 4), K), 256 threads
-__global__ __launch_bounds__(256) void track_boxes_kernel(TrackSet t)
+#if defined(F110_UNIT_CONSUMERS)
+static __global__ __launch_bounds__(256) void track_boxes_kernel(TrackSet t)
 {
     const int k = blockIdx.y;
     const int M = t.offsets[k + 1] - t.offsets[k], nseg = M - 1, nblk = (nseg + 63) >> 6;
@@ -373,6 +378,7 @@ __global__ __launch_bounds__(256) void track_boxes_kernel(TrackSet t)
         bx[0] = xl; bx[1] = xh; bx[2] = yl; bx[3] = yh; bx[4] = any_deg ? 1.0 : 0.0;
     }
 }
+#endif
 
 struct PlanTracksArgs {
     TrackSet t;
@@ -385,7 +391,8 @@ struct PlanTracksArgs {
 
 constexpr int PPG_WAVES = 4;
 
-__global__ __launch_bounds__(PPG_WAVES * 64) void pure_pursuit_tracks_kernel(PlanTracksArgs a)
+#if defined(F110_UNIT_CONSUMERS)
+static __global__ __launch_bounds__(PPG_WAVES * 64) void pure_pursuit_tracks_kernel(PlanTracksArgs a)
 {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int car = blockIdx.x * PPG_WAVES + wave;
@@ -518,5 +525,6 @@ __global__ __launch_bounds__(PPG_WAVES * 64) void pure_pursuit_tracks_kernel(Pla
         a.actions[(size_t)car * 2 + 1] = speed;
     }
 }
+#endif
 
 } // namespace f110

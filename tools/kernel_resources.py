@@ -13,10 +13,13 @@ if '--' in args:
     i = args.index('--')
     args, extra = args[:i], args[i + 1:]
 flt = args[0] if args else ''
-cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared',
-       '-Wno-unused-value', '-Rpass-analysis=kernel-resource-usage', '-o', '/tmp/_kres.so',
-       os.path.join(ROOT, 'red_gym_amd', 'csrc', 'f110_abi.hip')] + extra
-err = subprocess.run(cmd, stderr=subprocess.PIPE, universal_newlines=True).stderr
+sys.path.insert(0, ROOT)
+from red_gym_amd import build as _b  # noqa: E402
+err = ''
+for u in _b.UNITS:   # every translation unit of the library (device code only: -c of one unit at a time)
+    cmd = ['/opt/rocm/bin/hipcc'] + _b.FLAGS + ['-Rpass-analysis=kernel-resource-usage', '--cuda-device-only', '-c', '-o', '/dev/null',
+                                                os.path.join(_b.CSRC, u + '.hip')] + extra
+    err += subprocess.run(cmd, stderr=subprocess.PIPE, universal_newlines=True).stderr
 cur = None
 rows = []
 for line in err.splitlines():
