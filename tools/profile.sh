@@ -12,7 +12,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python3 $ROOT/bench.py --steps 20 --warmup 5 --sustained 0 --no-cpu-baseline --envs $ENVS --agents $AGENTS > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python3 $ROOT/bench.py --steps 20 --warmup 5 --sustained 0 --steady-state 0 --no-cpu-baseline --envs $ENVS --agents $AGENTS > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
 echo "stats rc=$?"
 pmc() { name=$1; shift; rocprofv3 --pmc "$@" --output-format csv -d $OUT/pmc_$name -o pmc -- python3 $ROOT/tools/sweep.py --steps 6 --warmup 30 --envs $ENVS --agents $AGENTS > $OUT/pmc_$name.out 2> $OUT/pmc_$name.err; echo "pmc $name rc=$?"; }
 pmc sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU

@@ -3,8 +3,8 @@
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 export TMPDIR=/tmp
 cd /tmp
-O=$ROOT/gpurun_out/prof_r04_default
-rocprofv3 --kernel-trace --stats --output-format csv -d $O -o bench -- python3 $ROOT/bench.py --no-cpu-baseline --sustained 0 > $O.json 2> $O.err
+O=$ROOT/gpurun_out/prof_r05_default
+rocprofv3 --kernel-trace --stats --output-format csv -d $O -o bench -- python3 $ROOT/bench.py --no-cpu-baseline --sustained 0 --steady-state 0 > $O.json 2> $O.err
 python3 - <<PY
 import csv,glob,json
 f=glob.glob('$O/**/*kernel_trace.csv',recursive=True)[0]
