@@ -403,6 +403,86 @@ __device__ inline void march_ident_pow2_fast(const MapView &m, double &x, double
           [magic] "s"(6755399441055744.0)
         : "vcc", "scc", "memory", "v60", "v61", "v62", "v63");
 }
+// The march for a map whose resolution is NOT a power of two (most F1TENTH maps: 0.05 m) and whose origin is not rotated, for
+// cars near their map (the same per-car test as above).  q = (x - ox) * (1 / res) is within ~2e-16 relative of the reference's
+// quotient (x - ox) / res, so its floor is the reference's cell unless q lies within 1e-9 of an integer: the loop computes the
+// fractions of both coordinates and LEAVES (flag = 1, nothing of the iteration done) when any marching ray is that close; the
+// caller then runs that one iteration through dist_lookup, which replays the reference's own division (cell_index), and comes
+// back.  Otherwise as march_ident_pow2_fast: floor by the magic number under round-toward -inf (and back to a double to form the
+// fraction), EXEC-masked, v_cmpx.  27 VALU + 7 SALU per iteration; the compiler's loop over dist_lookup is ~33 + ~20.
+// a wave-uniform double as a scalar-register operand (the compiler may hold it in vector registers where it feeds vector code)
+__device__ inline double uniform_f64(double v)
+{
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
+__device__ inline int march_ident_np_fast(const MapView &m, double &x, double &y, double &total, double &d, double c, double s,
+                                          double eps, double max_range, unsigned long long &am, int go, unsigned &nlook, int &nact)
+{
+    unsigned long long sx;
+    double qx, qy, fx, fy;
+    int flag;
+    // (wave-uniform by construction; said again for the register allocator: the values travel round a loop through compiler code)
+    am = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(am >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)am);
+    nlook = (unsigned)__builtin_amdgcn_readfirstlane((int)nlook);
+    nact = __builtin_amdgcn_readfirstlane(nact);
+    go = __builtin_amdgcn_readfirstlane(go);
+    asm volatile(
+        "s_mov_b64 %[sx], exec\n\t"
+        "s_mov_b64 exec, %[am]\n"
+        "1:\n\t"
+        "v_add_f64 %[qx], %[x], -%[ox]\n\t"
+        "v_add_f64 %[qy], %[y], -%[oy]\n\t"
+        "v_mul_f64 %[qx], %[rinv], %[qx]\n\t"
+        "v_mul_f64 %[qy], %[rinv], %[qy]\n\t"
+        "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 2\n\t"      // f64 rounding: toward -inf
+        "v_add_f64 v[60:61], %[qx], %[magic]\n\t"
+        "v_add_f64 v[62:63], %[qy], %[magic]\n\t"
+        "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 0\n\t"      // back to nearest-even
+        "v_add_f64 %[fx], v[60:61], -%[magic]\n\t"                // floor(q) as a double (exact)
+        "v_add_f64 %[fy], v[62:63], -%[magic]\n\t"
+        "v_add_f64 %[fx], %[qx], -%[fx]\n\t"                      // fraction (exact)
+        "v_add_f64 %[fy], %[qy], -%[fy]\n\t"
+        "v_add_f64 %[fx], %[fx], -0.5\n\t"
+        "v_add_f64 %[fy], %[fy], -0.5\n\t"
+        "v_max_f64 %[fx], |%[fx]|, |%[fy]|\n\t"
+        "v_cmp_lt_f64 vcc, %[thr], %[fx]\n\t"                     // a fraction within 1e-9 of 0 or 1
+        "s_cbranch_vccnz 3f\n\t"
+        "s_add_u32 %[nl], %[nl], %[na]\n\t"
+        "v_med3_i32 v62, v62, -1, %[H]\n\t"
+        "v_ashrrev_i32 v61, 3, v60\n\t"
+        "v_lshl_add_u32 v62, v62, 4, %[rb]\n\t"
+        "v_lshl_add_u32 v62, v60, 1, v62\n\t"
+        "v_mad_i32_i24 v61, v61, %[sm], v62\n\t"
+        "buffer_load_ushort v61, v61, %[rsrc], 0 offen\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        "ds_read_b64 %[d], v61\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_add_f64 %[tot], %[tot], %[d]\n\t"
+        "v_mul_f64 v[60:61], %[c], %[d]\n\t"
+        "v_mul_f64 v[62:63], %[s], %[d]\n\t"
+        "v_add_f64 %[x], %[x], v[60:61]\n\t"
+        "v_add_f64 %[y], %[y], v[62:63]\n\t"
+        "v_cmpx_lt_f64 vcc, %[eps], %[d]\n\t"
+        "v_cmpx_ge_f64 vcc, %[mr], %[tot]\n\t"
+        "s_bcnt1_i32_b64 %[na], exec\n\t"
+        "s_cmp_gt_i32 %[na], %[go]\n\t"
+        "s_cbranch_scc1 1b\n\t"
+        "s_mov_b32 %[flag], 0\n\t"
+        "s_branch 4f\n"
+        "3:\n\t"
+        "s_mov_b32 %[flag], 1\n"
+        "4:\n\t"
+        "s_mov_b64 %[am], exec\n\t"
+        "s_mov_b64 exec, %[sx]"
+        : [x] "+v"(x), [y] "+v"(y), [tot] "+v"(total), [d] "+v"(d), [am] "+s"(am), [nl] "+s"(nlook), [na] "+s"(nact), [sx] "=&s"(sx),
+          [qx] "=&v"(qx), [qy] "=&v"(qy), [fx] "=&v"(fx), [fy] "=&v"(fy), [flag] "=&s"(flag)
+        : [c] "v"(c), [s] "v"(s), [ox] "s"(uniform_f64(m.ox)), [oy] "s"(uniform_f64(m.oy)), [rinv] "s"(uniform_f64(m.rinv)), [H] "s"(m.H),
+          [rb] "s"(m.row_bias), [sm] "s"(m.strip_m16), [rsrc] "s"(m.cells_words), [eps] "s"(eps), [mr] "s"(max_range), [go] "s"(go),
+          [magic] "s"(6755399441055744.0), [thr] "s"(0.5 - 1e-9)
+        : "vcc", "scc", "memory", "v60", "v61", "v62", "v63");
+    return flag;
+}
 // the largest |cell coordinate| a look-up of the fast march may have: (c >> 3) * strip_bytes stays below 2^31 with room to
 // spare, and far inside the magic number's 2^31 (a NaN or infinite pose fails the test and takes the clamped loop)
 __device__ inline double march_fast_limit(const MapView &m) { return (double)((0x7fffffffu / (m.row_bias + 16u)) * 8u) - 64.0; }
@@ -653,9 +733,11 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
 #endif
         // (wave-uniform) may this car's rays take the fast march?  Every look-up lies within max_range of the car.
         bool fast = false;
-        if (IDENT && POW2) {
+        if (IDENT) {
             const double reach = max_range * mv.rinv + 2.0, lim = march_fast_limit(mv);
-            fast = fabs(__builtin_fma(px, mv.rinv, mv.nox)) + reach < lim && fabs(__builtin_fma(py, mv.rinv, mv.noy)) + reach < lim;
+            const double q0x = POW2 ? __builtin_fma(px, mv.rinv, mv.nox) : (px - mv.ox) * mv.rinv;
+            const double q0y = POW2 ? __builtin_fma(py, mv.rinv, mv.noy) : (py - mv.oy) * mv.rinv;
+            fast = fabs(q0x) + reach < lim && fabs(q0y) + reach < lim;
         }
         int next = 0;           // wave-uniform: next unassigned slot of the beam order
         bool active = false;
@@ -739,6 +821,27 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
                 unsigned long long am = vote(active);
                 if (fast) march_ident_pow2_fast(mv, x, y, total, d, c, s, eps, max_range, am, go, nlook, nact);
                 else march_ident_pow2(mv, x, y, total, d, c, s, eps, max_range, am, go, nlook, nact);
+                active = ((am >> lane) & 1ull) != 0ull;
+                continue;
+            }
+            if (IDENT && !POW2 && fast) {
+                unsigned long long am = vote(active);
+                while (march_ident_np_fast(mv, x, y, total, d, c, s, eps, max_range, am, go, nlook, nact)) {
+                    // a marching ray's quotient lies within 1e-9 of an integer: this one iteration through dist_lookup, which
+                    // replays the reference's own division for such lanes (cell_index)
+                    nlook += (unsigned)nact;
+                    bool act = __builtin_amdgcn_inverse_ballot_w64(am);
+                    if (act) {
+                        d = dist_lookup<IDENT, POW2>(mv, s_lut, x, y);
+                        total += d;
+                        x += d * c;
+                        y += d * s;
+                        act = (d > eps) && (total <= max_range);
+                    }
+                    am = vote(act);
+                    nact = __popcll(am);
+                    if (nact <= go) break;
+                }
                 active = ((am >> lane) & 1ull) != 0ull;
                 continue;
             }
