@@ -86,6 +86,38 @@ def test_scan_other_maps(assets, golden, name):
     e.close()
 
 
+@pytest.mark.parametrize('name', ['berlin', 'vegas'])
+def test_scan_quotients_on_cell_boundaries_other_maps(assets, name):
+    """Resolution 0.05: the march computes (x - ox) * (1 / res) and must fall back to the reference's own division
+    (laser_models.py:83-84) whenever that quotient lies within 1e-9 of an integer.  Poses whose y (or x) sits exactly on
+    a cell boundary, looking exactly along the other axis (yaw = pi with fov 2 pi puts beam 0 on LUT entry 0: cos 1, sin 0;
+    beam 270 / 540 / 810 on the other axes' entries): that beam's every look-up has an integer quotient in one coordinate, so
+    every march iteration of the wave takes the exit.  Poses far from the map take the clamped loop.  `==` the oracle, look-up
+    counts included."""
+    from red_gym_amd.engine import Engine
+    e = Engine(num_envs=1, num_agents=1, fov=2 * np.pi, noise_std=0)
+    e.set_map(os.path.join(assets, 'maps', name + '.yaml'), '.png')
+    s = oracle.Scanner(1080, 2 * np.pi)
+    s.set_map(os.path.join(assets, 'maps', name + '.yaml'), '.png')
+    m = s.map
+    dt, res, ox, oy = m['dt'], m['resolution'], m['orig_x'], m['orig_y']
+    rng = np.random.default_rng(17)
+    free = np.argwhere(dt > 0.4)
+    pick = free[rng.integers(0, len(free), 200)]
+    poses = []
+    for (r, c) in pick:
+        for yaw in (np.pi, 0.0, 0.5 * np.pi, 1.2345):
+            poses.append((ox + (c + 0.37) * res, oy + r * res, yaw))            # y on a boundary
+            poses.append((ox + c * res, oy + (r + 0.61) * res, yaw))            # x on a boundary
+            poses.append((ox + c * res, oy + r * res, yaw))                     # a cell corner
+    poses += [(ox + 3e6, oy + 1.0, 0.3), (ox - 2.5e7, oy - 4e6, 2.0), (1e12, -1e12, 1.0)]   # far away: the clamped loop
+    poses = np.array(poses)
+    ref, rlk = s.scan_batch(poses, return_lookups=True)
+    out, lk = e.scan(poses, want_lookups=True)
+    assert np.array_equal(_np(out), ref) and np.array_equal(_np(lk).astype(np.int64), rlk)
+    e.close()
+
+
 def test_scan_odd_config_and_fov47(assets, golden):
     from red_gym_amd.engine import Engine
     g = golden('g1_scan.npz')
