@@ -132,8 +132,14 @@ class Ranks(object):
         import datetime
         dist = self.dist
         tmo = datetime.timedelta(seconds=self.GROUP_TIMEOUT_S)
-        store = dist.TCPStore(os.environ['MASTER_ADDR'], int(os.environ['MASTER_PORT']), self.world, is_master=(self.rank == 0),
-                              timeout=tmo, wait_for_workers=False)
+        # Under torch.distributed.run the launcher's agent already HOSTS the store at MASTER_ADDR:MASTER_PORT
+        # (TORCHELASTIC_USE_AGENT_STORE=True, what torch's own env:// rendezvous looks at): every rank is then a client of it;
+        # self-launched ranks (python bench.py --gpus N) have no agent, and rank 0 hosts the store.
+        agent_store = os.environ.get('TORCHELASTIC_USE_AGENT_STORE') == 'True'
+        store = dist.TCPStore(os.environ['MASTER_ADDR'], int(os.environ['MASTER_PORT']), self.world,
+                              is_master=(self.rank == 0 and not agent_store), timeout=tmo, wait_for_workers=False)
+        if agent_store:   # (keys of an earlier attempt of the same launcher must not be seen)
+            store = dist.PrefixStore('f110_bench/attempt_%s' % os.environ.get('TORCHELASTIC_RESTART_COUNT', '0'), store)
         self._store = store
         fail_ranks = [int(r) for r in os.environ.get('F110_BENCH_TEST_PRIMARY_FAILS', '').split(',') if r.strip()]  # tests only
         err = None

@@ -131,6 +131,27 @@ def test_self_launch_starts_its_own_ranks():
     assert abs(out['value'] - 2 * 32 * 6 / (out['ms_per_step'] * 6e-3)) < 1e-6 * out['value']
 
 
+def test_ranks_started_by_torch_distributed_run():
+    """The driver's N > 1 form: `python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1
+    --master-port P bench.py --gpus 2 ...`.  The launcher's agent hosts the rendezvous store on that port, so the ranks must
+    join it as clients (rank 0 binding the port itself fails with "address already in use")."""
+    import json
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, F110_BENCH_BACKEND='gloo', F110_BENCH_STUB_STEP_MS='5')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT', 'MASTER_ADDR'):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1', '--envs', '16'],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240, text=True)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1 and lines[0]['n_gpus'] == 2 and lines[0]['steps'] == 4 and len(lines[0]['per_rank_ms']) == 2
+
+
 def test_self_launch_propagates_a_rank_failure():
     """A rank that dies must not leave the others waiting at a barrier: non-zero exit code, no JSON line."""
     rc, lines, err = _run_bench(['--gpus', '2', '--steps', '2', '--warmup', '0', '--envs', '8'],
