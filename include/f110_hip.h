@@ -284,6 +284,14 @@ int f110_set_scan_stages(f110_handle *h, const char *spec);
  * calls that change them -- f110_bind, f110_set_tables, every map install, f110_assign_maps / _params / _noise, a
  * re-allocation of the noise table -- bump the handle's launch epoch.  A graph captured at epoch e is valid while
  * f110_launch_epoch still reports e; after that it must be re-captured (F110VecEnv.step_graph does so itself). */
+/* Launch order of the step's scan (performance only; no reference counterpart): order_dev = dev int32 [num_envs * num_agents], a
+ * PERMUTATION of the car indices (the caller's responsibility: a wrong array scans some cars twice and others not at all), or NULL
+ * = car order.  The wave that would march car i marches car order[i]; every result is stored under the car's own index, so the
+ * outputs do not depend on it.  Purpose: cars that stand on the same noise row launched side by side share that row in the L1 / L2 --
+ * a batch whose envs were reset at different times otherwise streams one 8.6 KB row per env from HBM (10 % of the step at 65 536
+ * envs).  The array stays owned by the caller and may be re-written in stream order between steps (red_gym_amd.Engine re-sorts it
+ * by the envs' row counters every 64 steps); changing the POINTER moves the launch epoch.  Ignored while envs are on different maps. */
+int f110_set_scan_order(f110_handle *h, const int32_t *order_dev);
 int f110_launch_epoch(f110_handle *h, int64_t *epoch);
 
 /* The step as a HIP graph the library builds itself, for callers without a capturing framework and as the reference

@@ -83,6 +83,7 @@ SYMBOLS = {
     'f110_pack_env': [_VP, _I32, _VP, _VP],
     'f110_set_scan_stages': [_VP, C.c_char_p],
     'f110_launch_epoch': [_VP, C.POINTER(C.c_int64)],
+    'f110_set_scan_order': [_VP, _VP],
     'f110_graph_create': [_VP, _VP, _I32, C.POINTER(_VP)],
     'f110_graph_launch': [_VP, _VP],
     'f110_graph_info': [_VP, C.POINTER(C.c_int32), C.c_char_p],

@@ -119,6 +119,7 @@ struct f110_handle {
     PlanGrid plan_grid;
     uint8_t *d_plan_count = nullptr; uint16_t *d_plan_cand = nullptr;
     u128 *d_pcg_tab = nullptr;        // [2][65] powers and partial sums of the LCG multiplier (f110_noise.h NoiseGenArgs::pcg_tab)
+    const int32_t *scan_order = nullptr; // launch order of the step's scan (f110_set_scan_order; caller-owned device array) or NULL
     // per-env noise (f110_set_noise_per_env): every env its own generator and ONE row, produced in front of every step's scan
     bool per_env_noise = false;
     NoiseGen *d_env_gen = nullptr, *d_env_seed = nullptr;   // [num_envs]

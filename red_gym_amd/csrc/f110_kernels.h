@@ -527,6 +527,12 @@ struct ScanArgs {
     const uint8_t *pending_reset;// [B]
     int reset_only;              // 1: only envs with pending_reset are processed
     const uint16_t *chunk_beam0; // [ceil(nb/64)] first beam of the k-th 64-beam chunk to be marched (long rays first)
+    // Launch order (or NULL = car order): the wave that would march car i marches car order[i].  A permutation of the shard's
+    // cars that only changes WHICH wave marches WHICH car -- results are indexed by the car -- so that cars standing on the
+    // same noise row can be launched next to each other (f110_set_scan_order; Engine keeps it sorted by the envs' row counters:
+    // in a batch whose envs were reset at different times every env reads its own row, 566 MB per step at 65 536 envs, and the
+    // rows of neighbouring waves then come from the L1 / L2 instead of HBM).  Single-map handles only (a workgroup stages ONE LUT).
+    const int32_t *order;
     // outputs
     float *out_f32;              // [N,nb] or NULL
     double *out_f64;             // [N,nb] or NULL
@@ -595,7 +601,8 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
         wpc = 1 << lg; car = st < ns ? c + (t >> lg) : a.n_cars; part = t & (wpc - 1);
     }
     // the car's map (wave-uniform: scalar loads); waves past the last car still help to stage the LUT
-    const int car_c = rare->car_base + min(car, a.n_cars - 1);
+    int car_c = rare->car_base + min(car, a.n_cars - 1);
+    if (rare->order) car_c = rare->order[car_c]; // (launch position -> car; wave-uniform: a scalar load)
     const int env_c = a.agents == 1 ? car_c : car_c / a.agents; // (one agent: no division at run time)
     F110_BCHK(rare->n_stages >= 1 && rare->n_stages <= SCAN_MAX_STAGES, BT_STAGE_LIST, rare->dev_err);
     int map_slot = a.env_map ? a.env_map[env_c] : 0;
@@ -619,7 +626,7 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
     mv.init(md);
     F110_BOUNDS_ONLY(mv.err = rare->dev_err;)
     if (car >= a.n_cars) return;
-    car += rare->car_base; // (from here on the car's index in the shard)
+    car = car_c; // (from here on the car's index in the shard)
     // this wave's slice of the car's beam queue: chunk positions part, part+wpc, ...
     const int nch = (nb + 63) >> 6;
     const int my_chunks = nch > part ? (nch - part + wpc - 1) >> lg : 0;
@@ -783,7 +790,11 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
                 F110_BCHK((unsigned)b < (unsigned)nb, BT_NOISE_BEAM, rare->dev_err);
                 if ((unsigned)b >= (unsigned)nb) b = 0;
 #endif
+#if defined(F110_X_NONOISE) // timing experiment: the upper bound of what the noise gather costs (results invalid)
+                const double nsv = 0.0;
+#else
                 const double nsv = STEP ? *reinterpret_cast<const double *>(reinterpret_cast<const char *>(ns) + (size_t)((unsigned)b * 8u)) : 0.0;
+#endif
                 const double nzv = nz;
                 int ti = beam_theta_index(T0, t0w, b, a.scan, guard2);
 #if defined(F110_BOUNDS)

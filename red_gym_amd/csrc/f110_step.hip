@@ -232,6 +232,7 @@ static void fill_scan_args(const f110_handle *h, ScanArgs &s, int reset_only)
     s.side = h->d_side; s.side_max = h->side_max;
     s.noise_base = h->d_noise; s.noise_cap = (int)h->noise_cap; s.noise_mask = (int)(h->noise_cap - 1); s.noise_slots = h->noise_slots;
     s.env_noise = h->multi_noise ? h->d_env_noise : nullptr; s.dev_err = h->d_err;
+    s.order = (h->scan_order && !h->multi) ? h->scan_order : nullptr; // (a workgroup stages one LUT: car order when maps differ)
     if (h->per_env_noise) { s.noise_base = h->d_env_rows; s.noise_cap = 1; s.noise_mask = 0; s.noise_slots = c.num_envs; s.env_noise = h->d_env_ident; }
     s.beam_cosines = h->d_beam_cosines; s.ttc_thresh = c.ttc_thresh;
     s.in_collision = b.in_collision; s.pending_reset = b.pending_reset; s.reset_only = reset_only;
@@ -509,6 +510,15 @@ extern "C" int f110_set_scan_stages(f110_handle *h, const char *spec)
     }
     h->stages = spec ? spec : "";
     h->epoch++;
+    return F110_OK;
+}
+
+extern "C" int f110_set_scan_order(f110_handle *h, const int32_t *order_dev)
+{
+    if (!h) return fail(F110_E_INVALID, "f110_set_scan_order: null handle");
+    if (h->scan_order == order_dev) return F110_OK;
+    h->scan_order = order_dev;
+    h->epoch++; // the scan takes the pointer by value: a captured step is stale (the array's CONTENTS may change under it)
     return F110_OK;
 }
 

@@ -117,3 +117,33 @@ def test_fullsize_autoreset_bookkeeping():
             total_done += int(done2.sum())
     assert total_done > B // 50
     env.close()
+
+
+@pytest.mark.parametrize('B,A', [(16384, 1), (8192, 2)])
+def test_scan_launch_order_changes_no_result(B, A):
+    """f110_set_scan_order / Engine._reorder_scan: the wave that would march car i marches car order[i] -- a performance
+    device (cars on the same noise row side by side).  Two engines, same inputs, autoreset on, 200 steps of random driving (the
+    envs reset at different times, the sorted order is refreshed every 64 steps; the second engine additionally starts from a
+    RANDOM permutation set through the ABI): every output tensor `==` the car-order run, bit for bit."""
+    from red_gym_amd import workload
+    poses = torch.as_tensor(workload.spawn_poses(B, A))
+    acts = torch.as_tensor(workload.action_pool(8, B, A))
+    e0 = _mk(B, A, autoreset=True, count_lookups=True)
+    e0.eng.scan_reorder = False
+    e1 = _mk(B, A, autoreset=True, count_lookups=True)
+    perm = torch.randperm(B * A, generator=torch.Generator().manual_seed(3)).to(dtype=torch.int32, device=e1.device)
+    from red_gym_amd.engine import _lib, _ptr
+    _lib.check(e1.eng.lib.f110_set_scan_order(e1.eng._h, _ptr(perm)))
+    e0.reset(poses.to(e0.device)); e1.reset(poses.to(e1.device))
+    for k in range(200):
+        o0, _, d0, i0 = e0.step(acts[k % 8].to(e0.device))
+        o1, _, d1, i1 = e1.step(acts[k % 8].to(e1.device))
+        if k % 25 == 0 or k == 199:
+            assert torch.equal(o0['scans'], o1['scans']) and torch.equal(e0.state, e1.state), k
+            assert torch.equal(d0, d1) and torch.equal(o0['collisions'], o1['collisions']) and torch.equal(i0['toggles'], i1['toggles']), k
+            assert torch.equal(e0.eng.t['lookups'], e1.eng.t['lookups']), k
+    assert e1.eng._scan_order is not None and e1.eng._reorder_count > 128
+    srt = torch.sort(e1.eng._scan_order.to(torch.int64)).values
+    assert torch.equal(srt, torch.arange(B * A, device=e1.device))          # it is a permutation
+    assert int(e1.eng.t['noise_step'].max()) > int(e1.eng.t['noise_step'].min()) + 50   # the envs really stand on different rows
+    e0.close(); e1.close()
