@@ -329,7 +329,7 @@ class Engine(object):
             self._noise_to(target)   # not covered by a prefetch: produced now, in the caller's stream
 
     REORDER_EVERY = 64     # steps between two sorts of the scan's launch order
-    REORDER_MIN_CARS = 8192
+    REORDER_MIN_CARS = 65536  # (measured: +2.3 % in the steady state at 65 536 cars, neutral right after a reset; -1.3 % at 32 768 cars)
 
     def _reorder_scan(self):
         """Keeps the scan's launch order sorted by the envs' noise-row counters (f110_set_scan_order): envs that were reset at

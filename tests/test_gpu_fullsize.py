@@ -131,6 +131,7 @@ def test_scan_launch_order_changes_no_result(B, A):
     e0 = _mk(B, A, autoreset=True, count_lookups=True)
     e0.eng.scan_reorder = False
     e1 = _mk(B, A, autoreset=True, count_lookups=True)
+    e1.eng.REORDER_MIN_CARS = 1024        # (the engine sorts by itself from 65 536 cars on; here at every size)
     perm = torch.randperm(B * A, generator=torch.Generator().manual_seed(3)).to(dtype=torch.int32, device=e1.device)
     from red_gym_amd.engine import _lib, _ptr
     _lib.check(e1.eng.lib.f110_set_scan_order(e1.eng._h, _ptr(perm)))
