@@ -51,7 +51,7 @@ extern "C" {
 #define F110_MAX_CARS (1 << 26) /* num_envs * num_agents of one handle (32-bit wave / lane indices; offsets into the
                                   * per-car tensors are 64-bit): 67 M cars, 290 GB of fp32 scans alone at 1080 beams */
 #define F110_MAX_AGENTS 32
-#define F110_MAX_MAPS 64  /* map slots of one handle (f110_set_map_slot_*, f110_assign_maps) */
+#define F110_MAX_MAPS 4096  /* map slots of one handle (f110_set_map_slot_*, f110_assign_maps) */
 #define F110_MAX_NOISE_SLOTS 64 /* noise slots (= distinct seeds) of one handle (f110_set_noise_generator, f110_assign_noise) */
 #define F110_NOISE_INITIAL_ROWS 1024 /* rows per slot of a generated noise table when it is first allocated (it doubles on demand) */
 #define F110_NUM_PARAMS 18
@@ -165,8 +165,10 @@ int f110_track_mask(const double *pts_dev, int32_t n_pts, int32_t closed, int32_
 /* Map slots: one handle stands in for many F110Env instances, each of which may have its own map
  * (f110_env.py:100-157 takes `map` per env).  Slot 0 is the map of the calls above; f110_set_map_slot_* fill
  * slots 0..F110_MAX_MAPS-1 the same way, and f110_assign_maps gives every env its slot (host int32 [num_envs],
- * NULL = all envs on slot 0).  The cars of one scan workgroup (2 consecutive cars) must share a map, i.e.
- * assign maps to blocks of envs with an even car count.  Maps of different kinds ("resolution is a power of two",
+ * NULL = all envs on slot 0; F110_E_INDEX for a slot that holds no map).  Any assignment is valid.  The scan keeps its
+ * full occupancy when the 2 consecutive cars of every scan workgroup share a map, i.e. maps assigned to blocks of envs
+ * with an even car count; otherwise (a map per env) it runs one wave per workgroup, each staging its own map's table:
+ * same bits, ~24 % fewer env-steps/s at 65 536 cars (profiles/r05_map_per_env.txt).  Maps of different kinds ("resolution is a power of two",
  * "origin unrotated") may be mixed: the shard is then scanned block by block, each run of envs with the instantiation
  * its own maps allow (one more launch per change of kind along the env index). */
 int f110_set_map_slot_occupancy(f110_handle *h, int32_t slot, const uint8_t *free_mask_host, int32_t height, int32_t width,

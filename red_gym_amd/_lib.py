@@ -11,6 +11,7 @@ LIB_PATH = os.environ.get('F110_LIB') or os.path.join(_HERE, 'libf110_hip.so')  
 
 F110_MAX_AGENTS = 32
 F110_MAX_NOISE_SLOTS = 64
+F110_MAX_MAPS = 4096
 F110_NUM_PARAMS = 18
 F110_RK4, F110_EULER = 1, 2
 E_INVALID, E_HIP, E_NOMAP, E_INDEX, E_UNBOUND = -1, -2, -3, -4, -5

@@ -145,6 +145,7 @@ struct f110_handle {
     int32_t *d_env_map = nullptr;     // dev [B] slot of every env; only passed to the kernel when `multi`
     std::vector<int32_t> h_env_map;   // host copy (all 0 until f110_assign_maps)
     bool multi = false;
+    bool wg_single = false;           // some neighbouring cars stand on different maps: the scan runs one wave per workgroup
     bool ident = false, pow2 = false; // AND over the used slots: selects the scan_kernel instantiation
     double theta_inc = 0;
     // measurement aid (f110_profile_begin/end)

@@ -533,6 +533,10 @@ struct ScanArgs {
     // in a batch whose envs were reset at different times every env reads its own row, 566 MB per step at 65 536 envs, and the
     // rows of neighbouring waves then come from the L1 / L2 instead of HBM).  Single-map handles only (a workgroup stages ONE LUT).
     const int32_t *order;
+    // 1: workgroups of ONE wave (block = 64 threads) -- every car stages its own map's LUT, so neighbouring cars may stand on
+    // different maps (f110_assign_maps with a map per env); 0: SCAN_WAVES cars per workgroup share one LUT copy.
+    int wg_single;
+    int n_maps;             // slots of `maps` (bounds build)
     // outputs
     float *out_f32;              // [N,nb] or NULL
     double *out_f64;             // [N,nb] or NULL
@@ -584,7 +588,8 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
 #endif
     const int nb = a.scan.nb;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int wid = blockIdx.x * SCAN_WAVES + wave; // wave-uniform (scalar)
+    const int wg_single = rare->wg_single;
+    const int wid = wg_single ? (int)blockIdx.x : (int)blockIdx.x * SCAN_WAVES + wave; // wave-uniform (scalar)
     // wave -> (car, part of its beam queue).  Kept to one extra argument and shifts: this kernel sits at
     // the 80-SGPR budget of 8 waves/SIMD, and a scalar spilled inside the refill loop costs ~3 % of the launch.
     int wpc, car, part, lg; // (wpc = 2^lg: the divisions by it below are shifts -- a scalar integer division is ~25 dependent instructions)
@@ -607,16 +612,19 @@ __global__ __launch_bounds__(SCAN_THREADS, F110_SCAN_MIN_WAVES) void scan_kernel
     F110_BCHK(rare->n_stages >= 1 && rare->n_stages <= SCAN_MAX_STAGES, BT_STAGE_LIST, rare->dev_err);
     int map_slot = a.env_map ? a.env_map[env_c] : 0;
 #if defined(F110_BOUNDS)
-    F110_BCHK((unsigned)map_slot < 64u /* F110_MAX_MAPS */, BT_MAP_SLOT, rare->dev_err);
-    if ((unsigned)map_slot >= 64u) map_slot = 0;
+    F110_BCHK((unsigned)map_slot < (unsigned)rare->n_maps, BT_MAP_SLOT, rare->dev_err);
+    if ((unsigned)map_slot >= (unsigned)rare->n_maps) map_slot = 0;
 #endif
     const MapDev &md = a.maps[map_slot];
     {   // LDS image of the LUT prepared by the host (slot 0 = dt[-1,-1], last slot = the far marker): 16-B copies
         const double2 *src = reinterpret_cast<const double2 *>(md.lut_lds);
         double2 *dst = reinterpret_cast<double2 *>(s_lut);
         for (int i = threadIdx.x; i < LUT_LDS / 2; i += SCAN_THREADS) dst[i] = src[i];
+        if (SCAN_WAVES > 1 && wg_single) // (a lone wave copies the other waves' shares too)
+            for (int k = 1; k < SCAN_WAVES; k++)
+                for (int i = threadIdx.x + k * WAVE; i < LUT_LDS / 2; i += SCAN_THREADS) dst[i] = src[i];
     }
-    static_assert(MAX_CHUNKS <= SCAN_THREADS, "one pass stages the chunk table");
+    static_assert(MAX_CHUNKS <= WAVE, "one pass of one wave stages the chunk table");
     if ((int)threadIdx.x < ((nb + 63) >> 6)) s_chunk0[threadIdx.x] = a.chunk_beam0[threadIdx.x];
 #if defined(F110_TIMELINE)
     { unsigned long long t = wall_clock64(); asm volatile("" : "+v"(t)); if (lane == 0) s_tl[wave][0] = t; }

@@ -285,15 +285,16 @@ extern "C" int f110_get_map_slot_dt(f110_handle *h, int32_t slot, double *out)
 
 extern "C" int f110_get_map_dt(f110_handle *h, double *out) { return f110_get_map_slot_dt(h, 0, out); }
 
-// env -> map slot.  The cars of one scan workgroup (SCAN_WAVES consecutive cars) share the LDS copy of their
-// map's LUT, so they must be on the same map: with blocks of envs per map that holds whenever a block's car
-// count is a multiple of SCAN_WAVES.
+// env -> map slot.  The SCAN_WAVES consecutive cars of a scan workgroup share the LDS copy of their map's LUT; where
+// that holds for every workgroup (maps in blocks of envs whose car count is a multiple of SCAN_WAVES) the scan keeps that
+// shape.  Otherwise -- a map per env, odd blocks -- it runs one wave per workgroup, each staging its own car's LUT:
+// same results, fewer waves per CU (the LDS copies then cap a CU at 19 waves instead of 32).
 extern "C" int f110_assign_maps(f110_handle *h, const int32_t *map_of_env)
 {
     if (!h) return fail(F110_E_INVALID, "f110_assign_maps: null handle");
     const int B = h->cfg.num_envs, A = h->cfg.num_agents, N = B * A;
     std::vector<int32_t> m(B, 0);
-    bool multi = false;
+    bool multi = false, single = false;
     if (map_of_env)
         for (int e = 0; e < B; e++) {
             const int k = map_of_env[e];
@@ -302,20 +303,17 @@ extern "C" int f110_assign_maps(f110_handle *h, const int32_t *map_of_env)
             m[e] = k;
             multi = multi || k != 0;
         }
-    if (multi) {
-        if (N % SCAN_WAVES) return fail(F110_E_INVALID, "f110_assign_maps: %d cars is not a multiple of %d", N, SCAN_WAVES);
-        for (int c = 0; c < N; c += SCAN_WAVES)
-            for (int j = 1; j < SCAN_WAVES; j++)
-                if (m[(c + j) / A] != m[c / A])
-                    return fail(F110_E_INVALID, "f110_assign_maps: cars %d and %d share a scan workgroup but not a map "
-                                "(give every map a block of envs whose car count is a multiple of %d)", c, c + j, SCAN_WAVES);
-    }
+    if (multi)
+        for (int c = 0; c < N && !single; c += SCAN_WAVES)
+            for (int j = 1; j < SCAN_WAVES && c + j < N; j++)
+                if (m[(c + j) / A] != m[c / A]) { single = true; break; }
     ON_DEVICE(h->cfg.device);
     HIP_TRY(hipDeviceSynchronize()); // enqueued steps may still read the table
     if (!h->d_env_map) HIP_TRY(hipMalloc((void **)&h->d_env_map, sizeof(int32_t) * B));
     HIP_TRY(hipMemcpy(h->d_env_map, m.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice));
     h->h_env_map = m;
     h->multi = multi;
+    h->wg_single = single;
     h->epoch++;
     return F110_OK;
 }

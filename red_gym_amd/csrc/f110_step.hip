@@ -57,7 +57,7 @@ static int launch_scan_t(MapKind kind, const ScanArgs &a, const Sink &k, hipEven
 {
     int waves = 0;
     for (int i = 0; i < a.n_stages; i++) waves += a.stage_cars[i] << a.stage_log2w[i];
-    const dim3 grid((waves + SCAN_WAVES - 1) / SCAN_WAVES), block(SCAN_THREADS);
+    const dim3 grid(a.wg_single ? waves : (waves + SCAN_WAVES - 1) / SCAN_WAVES), block(a.wg_single ? WAVE : SCAN_THREADS);
     // sweeps only: F110_SCAN_PAD_LDS=<bytes> of unused dynamic LDS per workgroup caps the workgroups per CU (160 KiB / (8.6 KiB + pad)),
     // i.e. emulates a lower occupancy without touching the kernel
     static const unsigned pad_lds = getenv("F110_SCAN_PAD_LDS") ? (unsigned)atoi(getenv("F110_SCAN_PAD_LDS")) : 0u;
@@ -233,6 +233,7 @@ static void fill_scan_args(const f110_handle *h, ScanArgs &s, int reset_only)
     s.noise_base = h->d_noise; s.noise_cap = (int)h->noise_cap; s.noise_mask = (int)(h->noise_cap - 1); s.noise_slots = h->noise_slots;
     s.env_noise = h->multi_noise ? h->d_env_noise : nullptr; s.dev_err = h->d_err;
     s.order = (h->scan_order && !h->multi) ? h->scan_order : nullptr; // (a workgroup stages one LUT: car order when maps differ)
+    s.wg_single = h->multi && h->wg_single; s.n_maps = F110_MAX_MAPS;
     if (h->per_env_noise) { s.noise_base = h->d_env_rows; s.noise_cap = 1; s.noise_mask = 0; s.noise_slots = c.num_envs; s.env_noise = h->d_env_ident; }
     s.beam_cosines = h->d_beam_cosines; s.ttc_thresh = c.ttc_thresh;
     s.in_collision = b.in_collision; s.pending_reset = b.pending_reset; s.reset_only = reset_only;
@@ -585,7 +586,7 @@ extern "C" int f110_scan(f110_handle *h, const double *poses, int32_t n, double 
     if (int rc = check_device(h, "f110_scan")) return rc;
     ScanArgs s;
     memset(&s, 0, sizeof(s));
-    s.maps = h->d_maps; s.scan = scan_dev(h); s.n_cars = n; s.agents = 1;
+    s.maps = h->d_maps; s.n_maps = F110_MAX_MAPS; s.scan = scan_dev(h); s.n_cars = n; s.agents = 1;
     s.pose_src = poses; s.pose_stride = 3; s.yaw_off = 2;
     s.out_f32 = out32; s.out_f64 = out64; s.lookups = lookups; s.chunk_beam0 = h->d_chunk0;
     Sink k;

@@ -398,8 +398,10 @@ class Engine(object):
             self.map = ('dt', (H, W))
 
     def assign_maps(self, map_of_env=None):
-        """Gives every env its map slot (int array [num_envs]; None: all on slot 0).  Maps go to blocks of envs whose
-        car count is even (the two cars of a scan workgroup share a map); ValueError / IndexError otherwise."""
+        """Gives every env its map slot (int array [num_envs] of used slots 0.._lib.F110_MAX_MAPS-1; None: all on slot 0;
+        IndexError for a slot that holds no map).  Any pattern works; the scan keeps its full occupancy when maps go to
+        blocks of envs with an even car count (the two cars of a scan workgroup then share one copy of their map's table),
+        and runs one wave per workgroup otherwise (a map per env: about a quarter slower, same bits)."""
         if map_of_env is None:
             _lib.check(self.lib.f110_assign_maps(self._h, None))
             return

@@ -34,6 +34,10 @@ def test_struct_layouts_match_header():
     fields = re.findall(r'\*\s*([a-z_0-9]+);', body)
     assert fields == _lib.BUFFER_FIELDS
     assert C.sizeof(_lib.Config) == 8 * 4 + 5 * 8 + 18 * 8
+    # the limits the Python mirror checks against are the header's
+    for name in ('F110_MAX_AGENTS', 'F110_MAX_NOISE_SLOTS', 'F110_MAX_MAPS', 'F110_NUM_PARAMS'):
+        m = re.search(r'#define\s+%s\s+\(?(\d+)' % name, hdr)
+        assert m and int(m.group(1)) == getattr(_lib, name), name
 
 
 def test_error_reporting_without_gpu(lib):

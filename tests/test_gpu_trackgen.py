@@ -212,14 +212,56 @@ def test_map_slots_give_env_blocks_their_own_map():
     assert np.array_equal(multi.eng.get_map_dt(slot=1), singles[1].eng.get_map_dt())
     # the maps differ, so the blocks really see different worlds
     assert not torch.equal(outs[0]['scans'], outs[1]['scans'])
-    # error behaviour: unused slot, odd split of a workgroup
+    # error behaviour: a slot that holds no map
     with pytest.raises(IndexError):
         multi.eng.assign_maps(np.full(B, 5))
-    bad = np.zeros(B, dtype=np.int32); bad[1:] = 1
-    with pytest.raises(ValueError):
-        multi.eng.assign_maps(bad)
     multi.eng.assign_maps(None)
     assert torch.equal(multi.reset(poses)[0]['scans'], singles[0].reset(poses)[0]['scans'])
+    for e in [multi] + singles:
+        e.close()
+
+
+def test_a_map_per_env_neighbouring_cars_on_different_maps():
+    """f110_assign_maps without the block rule: envs take their maps in any pattern (here env e on map e % 4, an odd number of
+    envs, slots far beyond the first 64) -- the scan then runs one wave per workgroup, every car staging its own map's table --
+    and every env still scans, collides and steps exactly like a single-map env on its map."""
+    from red_gym_amd import F110VecEnv, workload, maps
+    from red_gym_amd import _lib
+    B = 97
+    multi = F110VecEnv(B, map=workload.EXAMPLE_MAP, num_agents=1)
+    names = [None, 'berlin', 'skirk', 'rot']
+    slots = [0, 65, 1000, _lib.F110_MAX_MAPS - 1]
+    specs = []
+    for k, name in zip(slots, names):
+        y = workload.EXAMPLE_MAP + '.yaml' if name in (None, 'rot') else maps.builtin_map_yaml(name)
+        m = maps.load_map(y, '.png')
+        theta = 0.3 if name == 'rot' else float(np.arctan2(m.orig_s, m.orig_c))
+        specs.append((m.free, m.resolution, m.orig_x, m.orig_y, theta))
+        multi.eng.set_map_occupancy(*specs[-1], slot=k)
+    with pytest.raises(IndexError):
+        multi.eng.set_map_occupancy(*specs[0], slot=_lib.F110_MAX_MAPS)
+    which = np.arange(B) % 4
+    rng = np.random.default_rng(1)
+    poses = np.zeros((B, 1, 3))
+    poses[:, 0, :2] = rng.uniform(-3, 3, (B, 2))
+    poses[:, 0, 2] = rng.uniform(-3, 3, B)
+    acts = workload.action_pool(4, B, 1)
+    singles = [F110VecEnv(B, map=workload.EXAMPLE_MAP, num_agents=1) for n in names]
+    for sgl, spec in zip(singles, specs):
+        sgl.eng.set_map_occupancy(*spec)
+    # all four kinds interleaved (one launch per run of envs of a kind), then the two maps of one kind only (one launch)
+    for pattern in (which, np.where(which % 2 == 0, 0, 3)):
+        multi.eng.assign_maps(np.asarray(slots)[pattern])
+        om = multi.reset(poses)[0]
+        outs = [s.reset(poses)[0] for s in singles]
+        for step in range(4):
+            for k in set(pattern.tolist()):
+                sel = torch.as_tensor(pattern == k, device=multi.device)
+                assert torch.equal(om['scans'][sel], outs[k]['scans'][sel]), (step, k)
+                assert torch.equal(om['collisions'][sel], outs[k]['collisions'][sel])
+            om = multi.step(acts[step])[0]
+            outs = [s.step(acts[step])[0] for s in singles]
+    assert not torch.equal(outs[0]['scans'][0], outs[3]['scans'][0])
     for e in [multi] + singles:
         e.close()
 
