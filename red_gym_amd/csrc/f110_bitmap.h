@@ -10,6 +10,9 @@
 //     of FillEdgeCollection's active-edge list), crossings x(y) = x0 + (y - y0)*dx in 48.16 fixed point;
 //   * all drawing is one colour, so outline, fill and markers are OR-ed into a 1-bit image in LDS and the
 //     grey levels / channels are expanded only when the image is streamed out (the only HBM write).
+// Segments: a lidar polygon's edges are a few pixels long, so an edge inside the image with at most BM_DIRECT items is
+// drawn by its own thread straight from the points; the rest (long edges, clipLine cases, every ray) goes through
+// 32-byte records whose items the threads share evenly (profiles/r05_bitmap.txt).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -39,6 +42,7 @@ struct BitmapArgs {
     double scale;
     unsigned char *out;      // [n, rows, cols(, channels)]
     int S;                   // words per bit-plane row (cols/32 rounded up, made odd)
+    int qcap;                // segment records held in LDS at a time (bm_queue_cap)
 };
 
 // One segment / polygon edge, ready to be walked item by item (32 bytes, two ds_read_b128):
@@ -53,12 +57,50 @@ struct alignas(16) EdgeRec {
     long long x, dx;     // crossing at row ya and its per-row increment
 };
 
-__host__ __device__ inline size_t bitmap_lds_bytes(int T, int rows, int S)
+// Segments drawn straight from the points (no record): both ends inside the image and at most this many items.
+#ifndef F110_BM_DIRECT
+#define F110_BM_DIRECT 8
+#endif
+constexpr int BM_DIRECT = F110_BM_DIRECT;
+#ifndef F110_BM_X
+#define F110_BM_X 0   // experiments only (tools/build_variant.sh): 1 = no segments drawn, 2 = no parity pass, 4 = no points
+#endif
+#ifndef F110_BM_MIN_SHARE
+#define F110_BM_MIN_SHARE 1
+#endif
+constexpr int BM_MIN_SHARE = F110_BM_MIN_SHARE; // items per thread of the record path's walk, at least
+
+// LDS of one image (byte offsets, each on a 16-byte boundary):
+//   recs  EdgeRec[qcap]   records of the queued segments of one round (later the 2 KB grey-level table)
+//   pts   int2[T]         the polygon's points
+//   par   u32[rows*S] + carry bits[rows/32]   crossing parity plane (FILL only: no bytes in the other modes)
+//   any   u32[rows*S]     the 1-bit image
+//   queue u16[T]          queued segments: inside the image from the front, needing clipLine from the back
+//   start int[qcap+1]     exclusive prefix of the round's item counts
+struct BmLayout { unsigned recs, pts, par, any, queue, start, bytes; };
+__host__ __device__ inline BmLayout bm_layout(int T, int rows, int S, int qcap, int mode)
 {
-    // EdgeRec[T] | { par[rows*S] | carry bits[rows/32] } overlaid on { pts int2[T] } | start int[T+1] | any[rows*S]
-    const size_t par = (size_t)rows * S * 4 + (size_t)((rows + 31) / 32) * 4, pts = (size_t)T * 8;
-    return (size_t)T * sizeof(EdgeRec) + (size_t)(T + 1) * 4 + (size_t)rows * S * 4 + (par > pts ? par : pts);
+    BmLayout l;
+    auto up = [](unsigned v) { return (v + 15u) & ~15u; };
+    l.recs = 0;
+    l.pts = up((unsigned)qcap * (unsigned)sizeof(EdgeRec) < 2048u ? 2048u : (unsigned)qcap * (unsigned)sizeof(EdgeRec));
+    l.par = up(l.pts + (unsigned)T * 8u);
+    l.any = up(l.par + (mode == BM_FILL ? ((unsigned)rows * S + (unsigned)((rows + 31) / 32)) * 4u : 0u));
+    l.queue = up(l.any + (unsigned)rows * S * 4u);
+    l.start = up(l.queue + (unsigned)T * 2u);
+    l.bytes = up(l.start + (unsigned)(qcap + 1) * 4u);
+    return l;
 }
+// Records per round.  RAYS queues every segment (centre -> point, plus its marker); FILL / POLYGON queue only what the
+// direct pass leaves: long edges and the ones that need clipLine -- a few per cent on a lidar polygon.  More queued
+// segments than records are drawn in several rounds (drawing is OR / XOR into the planes: any order, any grouping).
+__host__ __device__ inline int bm_queue_cap(int T, int mode)
+{
+    if (mode == BM_RAYS) return T;
+    const int c = (T + 3) / 4 < 128 ? 128 : (T + 3) / 4;
+    return c < T ? c : T;
+}
+__host__ __device__ inline size_t bitmap_lds_bytes(int T, int rows, int S, int mode) { return bm_layout(T, rows, S, bm_queue_cap(T, mode), mode).bytes; }
 
 // cv::clipLine(Size2l, Point2l&, Point2l&), drawing.cpp
 __device__ inline bool bm_clip_line(long long width, long long height, long long &x1, long long &y1, long long &x2, long long &y2)
@@ -266,172 +308,238 @@ static __global__ __launch_bounds__(256) void bitmap_points_kernel(BitmapArgs a,
 #endif
 
 #if defined(F110_UNIT_CONSUMERS)
-static __global__ __launch_bounds__(BM_THREADS) void bitmap_kernel(BitmapArgs a)
+static __global__ __launch_bounds__(BM_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void bitmap_kernel(BitmapArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     __shared__ int s_wave[BM_THREADS / 64];
-    const int T = a.T, rows = a.rows, cols = a.cols, S = a.S, tid = threadIdx.x, mode = a.mode;
-    EdgeRec *recs = reinterpret_cast<EdgeRec *>(s_raw);
-    unsigned *parp = reinterpret_cast<unsigned *>(s_raw + (size_t)T * sizeof(EdgeRec));
+    __shared__ int s_nq[2]; // queued segments: [0] inside the image, [1] needing clipLine
+    // the direct pass's crossing increments: floor((|dx| << 16) / |dy|) for |dx|, |dy| < 8 -- the quotient PolyEdge's
+    // int64 division truncates toward zero is sign * this; a table look-up instead of an fp64 division per edge
+    __shared__ int s_fdx[64];
+    static_assert(BM_DIRECT <= 8, "s_fdx holds the increments of edges of at most 8 items");
+    const int T = a.T, rows = a.rows, cols = a.cols, S = a.S, tid = threadIdx.x, mode = a.mode, qcap = a.qcap;
+    const int lane = tid & 63;
+    const BmLayout lay = bm_layout(T, rows, S, qcap, mode);
+    EdgeRec *recs = reinterpret_cast<EdgeRec *>(s_raw + lay.recs);
+    int2 *pts = reinterpret_cast<int2 *>(s_raw + lay.pts);
+    unsigned *parp = reinterpret_cast<unsigned *>(s_raw + lay.par);
     unsigned *carry = parp + rows * S;                   // one bit per row
-    int2 *pts = reinterpret_cast<int2 *>(parp);          // dead once the records exist; par / carry are zeroed after that
-    const int par_words = rows * S + (rows + 31) / 32;
-    int *start = reinterpret_cast<int *>(parp + max(par_words, 2 * T));
-    unsigned *anyp = reinterpret_cast<unsigned *>(start + T + 1);
+    unsigned *anyp = reinterpret_cast<unsigned *>(s_raw + lay.any);
+    unsigned short *queue = reinterpret_cast<unsigned short *>(s_raw + lay.queue);
+    int *start = reinterpret_cast<int *>(s_raw + lay.start);
 
     const int img = blockIdx.x;
     const int cx = rows / 2, cy = cols / 2; // lidar.py:75: center = (dims[0]//2, dims[1]//2), used as (x, y)
 
     // lidar.py:70-81: points = rint(center + (scaling_factor * data) * {cos, sin}(angles)).astype(int)
-    for (int k = tid; k < T; k += BM_THREADS) pts[k] = bm_point(a, img, k, cx, cy);
-    __syncthreads();
-
-    // ---- one record per segment: polygon edges pts[i-1] -> pts[i] (FILL, POLYGON) or rays centre -> pts[i].
-    // Two passes: segments inside the image (most of them) take the short 32-bit set-up; the ones that need clipLine's
-    // 64-bit arithmetic and fp64 divisions are queued and set up afterwards by the first threads only -- in one pass every
-    // wave would run the long form for its few outside segments.  Item counts go through start[] (scanned below).
-    __shared__ int s_nout;
-    // the queue of outside segments (<= T ints) sits behind the points if the parity plane they are overlaid on has the
-    // room, else in the (not yet used) image plane; an image too small for either sets every segment up the long way
-    int *outq = par_words >= 3 * T ? reinterpret_cast<int *>(parp + 2 * T) : rows * S >= T ? reinterpret_cast<int *>(anyp) : nullptr;
-    if (tid == 0) s_nout = 0;
-    __syncthreads();
-    for (int i = tid; i < T; i += BM_THREADS) {
-        const int2 p1 = pts[i];
-        const int2 p0 = mode == BM_RAYS ? make_int2(cx, cy) : pts[i == 0 ? T - 1 : i - 1];
-        const bool outside = (unsigned)p0.x >= (unsigned)cols || (unsigned)p1.x >= (unsigned)cols ||
-                             (unsigned)p0.y >= (unsigned)rows || (unsigned)p1.y >= (unsigned)rows;
-        if (outside && outq) outq[atomicAdd(&s_nout, 1)] = i;
-        else if (outside) {
-            EdgeRec r;
-            start[i] = bm_edge_setup(mode, rows, cols, p0, p1, r);
-            recs[i] = r;
-        } else {
-            EdgeRec r;
-            start[i] = bm_edge_setup_inside(mode, p0, p1, r);
-            recs[i] = r;
-        }
-    }
-    __syncthreads();
-    for (int j = tid; j < s_nout; j += BM_THREADS) {
-        const int i = outq[j];
-        const int2 p1 = pts[i];
-        const int2 p0 = mode == BM_RAYS ? make_int2(cx, cy) : pts[i == 0 ? T - 1 : i - 1];
-        EdgeRec r;
-        start[i] = bm_edge_setup(mode, rows, cols, p0, p1, r);
-        recs[i] = r;
-    }
-    __syncthreads();
-    // exclusive prefix of the item counts, in place: thread t owns segments t*per .. t*per + per - 1
-    const int per = (T + BM_THREADS - 1) / BM_THREADS;
-    int cnt[BM_PER_MAX], local = 0;
-#pragma unroll
-    for (int q = 0; q < BM_PER_MAX; q++) {
-        const int i = tid * per + q;
-        cnt[q] = (q < per && i < T) ? start[i] : 0;
-        local += cnt[q];
-    }
-    int total;
-    int base = bm_block_scan(local, total, s_wave);
-#pragma unroll
-    for (int q = 0; q < BM_PER_MAX; q++) {
-        const int i = tid * per + q;
-        if (q < per && i < T) { start[i] = base; base += cnt[q]; }
-    }
-    if (tid == 0) start[T] = total;
-    // zero both planes (anyp held the queue of outside segments; every thread is past its pts reads: barrier in the scan)
-    // -- 16 bytes per store where the plane starts on a 16-byte boundary (the records before it are 32 bytes each)
+    for (int k = tid; k < ((F110_BM_X & 4) ? 0 : T); k += BM_THREADS) pts[k] = bm_point(a, img, k, cx, cy);
+    // zero both planes (contiguous, each on a 16-byte boundary: 16 bytes per store)
     {
         uint4 *z4 = reinterpret_cast<uint4 *>(parp);
-        const int n4 = par_words >> 2;
+        const int n4 = (int)((lay.queue - lay.par) >> 4);
         for (int i = tid; i < n4; i += BM_THREADS) z4[i] = make_uint4(0u, 0u, 0u, 0u);
-        for (int i = (n4 << 2) + tid; i < par_words; i += BM_THREADS) parp[i] = 0u;
-        const int nw = rows * S, head = (int)(((16u - ((unsigned)(size_t)anyp & 15u)) & 15u) >> 2); // words up to the next boundary
-        for (int i = tid; i < min(head, nw); i += BM_THREADS) anyp[i] = 0u;
-        uint4 *a4 = reinterpret_cast<uint4 *>(anyp + head);
-        const int m4 = nw > head ? (nw - head) >> 2 : 0;
-        for (int i = tid; i < m4; i += BM_THREADS) a4[i] = make_uint4(0u, 0u, 0u, 0u);
-        for (int i = head + (m4 << 2) + tid; i < nw; i += BM_THREADS) anyp[i] = 0u;
     }
+    if (tid < 2) s_nq[tid] = 0;
+    if (tid < 64) s_fdx[tid] = (tid & 7) ? ((tid >> 3) << BM_XY_SHIFT) / (tid & 7) : 0;
+    __syncthreads();
     if (a.draw_center && mode != BM_FILL && tid < 25) {
         // lidar.py:98-100: centre marker in the draw colour (FILL clears it after the fill, below)
         const int x = cx - 2 + tid % 5, y = cy - 2 + tid / 5;
         if ((unsigned)x < (unsigned)cols && (unsigned)y < (unsigned)rows) bm_set(anyp, S, x, y);
     }
-    __syncthreads();
 
-    // ---- walk the items: every thread takes a contiguous share of all segments' pixels / crossings / marker pixels
-    {
-        const int ipt = (total + BM_THREADS - 1) / BM_THREADS;
-        int j = tid * ipt;
-        const int jend = min(j + ipt, total);
-        if (j < jend) {
-            int e = bm_find(start, T, j);
-            int k = j - start[e], n_items = start[e + 1] - start[e];
-            EdgeRec r = recs[e];
-            int L = (r.lin >> 28) ? (int)(r.lin & 0x1fffu) + 1 : 0;
-            // Bresenham state after k major steps: minor offset m, error term err (LineIterator's recurrence in closed form)
-            int dmaj = (int)(r.lin & 0x1fffu), dmin = (int)((r.lin >> 13) & 0x1fffu);
-            int m = (k > 0 && k < L) ? (2 * dmin * k + dmaj - 1) / (2 * dmaj) : 0;
-            int err = dmaj - 2 * dmin * (k + 1) + 2 * dmaj * m;
-            long long xr = r.x + (long long)(k > L ? k - L : 0) * r.dx;
-            for (; j < jend; j++, k++) {
-                while (k >= n_items) {   // next segment with at least one item
-                    e++;
-                    n_items = start[e + 1] - start[e];
-                    k = 0;
-                    if (n_items > 0) {
-                        r = recs[e];
-                        L = (r.lin >> 28) ? (int)(r.lin & 0x1fffu) + 1 : 0;
-                        dmaj = (int)(r.lin & 0x1fffu); dmin = (int)((r.lin >> 13) & 0x1fffu);
-                        m = 0; err = dmaj - 2 * dmin;
-                        xr = r.x;
-                    }
-                }
-                if (k < L) {
-                    const int x0 = (int)(r.xy0 & 0xffffu), y0 = (int)(r.xy0 >> 16);
-                    const int sy = (r.lin >> 26) & 1u ? -1 : 1;
-                    const bool vert = (r.lin >> 27) & 1u;
-                    const int x = vert ? x0 + m : x0 + k, y = vert ? y0 + sy * k : y0 + sy * m;
-                    bm_set(anyp, S, x, y);
-                    const int neg = err < 0;
-                    err += (neg ? 2 * dmaj : 0) - 2 * dmin;
-                    m += neg;
-                } else if (mode == BM_FILL) {
-                    const int y = (int)(r.rows & 0xffffu) + (k - L);
-                    const long long X = xr >> BM_XY_SHIFT;
-                    xr += r.dx;
-                    if (X < 0) atomicXor(&carry[y >> 5], 1u << (y & 31));
-                    else if (X < cols) {
-                        atomicXor(&parp[__mul24(y, S) + (int)(X >> 5)], 1u << (X & 31));
-                        bm_set(anyp, S, (int)X, y);
-                    }
-                } else {
-                    const int q = k - L;
-                    const int x = (int)(short)(r.mark & 0xffff) - 2 + q % 5, y = (r.mark >> 16) - 2 + q / 5;
-                    if ((unsigned)x < (unsigned)cols && (unsigned)y < (unsigned)rows) bm_set(anyp, S, x, y);
+    // ---- the segments: polygon edges pts[i-1] -> pts[i] (FILL, POLYGON) or rays centre -> pts[i].
+    // Direct pass, one segment per thread: an edge of a lidar polygon joins two neighbouring beams' end points -- a handful
+    // of pixels (90 % of them <= 4 items, profiles/r05_bitmap.txt).  An edge with both ends inside the image and at most
+    // BM_DIRECT items is drawn here and now, from registers: Bresenham pixels by LineIterator's recurrence, crossings by
+    // the 16.16 increment (32 bits suffice: x stays between the two end points).  Everything else -- long edges, edges that
+    // need clipLine's 64-bit arithmetic, every ray -- is queued for the record path below, where threads share items, not segments.
+    for (int i0 = 0; i0 < ((F110_BM_X & 1) ? 0 : T); i0 += BM_THREADS) {
+        const int i = i0 + tid;
+        const bool valid = i < T;
+        int2 p0 = make_int2(0, 0), p1 = p0;
+        if (valid) {
+            p1 = pts[i];
+            p0 = mode == BM_RAYS ? make_int2(cx, cy) : pts[i == 0 ? T - 1 : i - 1];
+        }
+        const bool outside = (unsigned)p0.x >= (unsigned)cols || (unsigned)p1.x >= (unsigned)cols ||
+                             (unsigned)p0.y >= (unsigned)rows || (unsigned)p1.y >= (unsigned)rows;
+        int x1 = p0.x, y1 = p0.y, dx = p1.x - p0.x, dy = p1.y - p0.y;
+        if (dx < 0) { dx = -dx; dy = -dy; x1 = p1.x; y1 = p1.y; }      // leftToRight
+        const int sy = dy < 0 ? -1 : 1, ady = dy < 0 ? -dy : dy;
+        const bool vert = ady > dx;
+        const int dmaj = vert ? ady : dx, dmin = vert ? dx : ady;
+        const int R = mode == BM_FILL ? ady : 0;
+        const bool direct = valid && !outside && mode != BM_RAYS && dmaj + 1 + R <= BM_DIRECT;
+        // queue positions by wave-wide counts: one LDS atomic per wave and queue
+        const bool q_in = valid && !outside && !direct, q_out = valid && outside;
+        const unsigned long long m_in = __ballot(q_in), m_out = __ballot(q_out);
+        if (m_in | m_out) {
+            const unsigned long long below = (1ull << lane) - 1ull;
+            int b_in = 0, b_out = 0;
+            if (lane == 0) {
+                if (m_in) b_in = atomicAdd(&s_nq[0], __popcll(m_in));
+                if (m_out) b_out = atomicAdd(&s_nq[1], __popcll(m_out));
+            }
+            b_in = __shfl(b_in, 0, 64); b_out = __shfl(b_out, 0, 64);
+            if (q_in) queue[b_in + __popcll(m_in & below)] = (unsigned short)i;
+            if (q_out) queue[T - 1 - (b_out + __popcll(m_out & below))] = (unsigned short)i;
+        }
+        if (direct) {
+            int m = 0, err = dmaj - 2 * dmin;
+            for (int k = 0; k <= dmaj; k++) {
+                const int x = vert ? x1 + m : x1 + k, y = vert ? y1 + sy * k : y1 + sy * m;
+                bm_set(anyp, S, x, y);
+                const int neg = err < 0;
+                err += (neg ? 2 * dmaj : 0) - 2 * dmin;
+                m += neg;
+            }
+            if (R > 0) {   // (the crossing items of bm_edge_setup_inside's record: x from the end point with the smaller y)
+                const int half = 1 << (BM_XY_SHIFT - 1);
+                const int fdx = sy * s_fdx[dx * 8 + ady]; // == (int)((double)((p1.x - p0.x) << 16) / (double)(p1.y - p0.y))
+                int xr = ((p0.y < p1.y ? p0.x : p1.x) << BM_XY_SHIFT) + half;
+                const int ya = p0.y < p1.y ? p0.y : p1.y;
+                for (int j = 0; j < R; j++) {
+                    const int X = xr >> BM_XY_SHIFT, y = ya + j;
+                    xr += fdx;
+                    atomicXor(&parp[__mul24(y, S) + (X >> 5)], 1u << (X & 31));
+                    bm_set(anyp, S, X, y);
                 }
             }
         }
     }
     __syncthreads();
 
+    // ---- record path: rounds of at most qcap queued segments -- records, prefix of their item counts, item walk
+    const int n_in = s_nq[0], nq = n_in + s_nq[1];
+    for (int q0 = 0; q0 < nq; q0 += qcap) {
+        const int nr = min(qcap, nq - q0);
+        // records: the inside segments take the short 32-bit set-up, the ones that need clipLine's 64-bit arithmetic and
+        // fp64 divisions the long one -- in separate loops, so that a wave runs the long form only if it holds such a segment
+        for (int pass = 0; pass < 2; pass++) {
+            const int j0 = pass == 0 ? q0 : max(q0, n_in), j1 = pass == 0 ? min(q0 + nr, n_in) : q0 + nr;
+            for (int j = j0 + tid; j < j1; j += BM_THREADS) {
+                const int i = pass == 0 ? queue[j] : queue[T - 1 - (j - n_in)];
+                const int2 p1 = pts[i];
+                const int2 p0 = mode == BM_RAYS ? make_int2(cx, cy) : pts[i == 0 ? T - 1 : i - 1];
+                EdgeRec r;
+                start[j - q0] = pass == 0 ? bm_edge_setup_inside(mode, p0, p1, r) : bm_edge_setup(mode, rows, cols, p0, p1, r);
+                recs[j - q0] = r;
+            }
+        }
+        __syncthreads();
+        // exclusive prefix of the item counts, in place
+        int total;
+        if (nr <= 64) {
+            // (the usual case of FILL / POLYGON: a few dozen queued segments -- one wave, no block-wide scan)
+            if (tid < 64) {
+                const int v = tid < nr ? start[tid] : 0;
+                int incl = v;
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int t = __shfl_up(incl, off, 64);
+                    if (lane >= off) incl += t;
+                }
+                if (tid < nr) start[tid] = incl - v;
+                if (tid == 63) start[nr] = incl;
+            }
+            __syncthreads();
+            total = start[nr];
+        } else {
+            // thread t owns records t*per .. t*per + per - 1
+            const int per = (nr + BM_THREADS - 1) / BM_THREADS;
+            int cnt[BM_PER_MAX], local = 0;
+#pragma unroll
+            for (int q = 0; q < BM_PER_MAX; q++) {
+                const int i = tid * per + q;
+                cnt[q] = (q < per && i < nr) ? start[i] : 0;
+                local += cnt[q];
+            }
+            int base = bm_block_scan(local, total, s_wave);
+#pragma unroll
+            for (int q = 0; q < BM_PER_MAX; q++) {
+                const int i = tid * per + q;
+                if (q < per && i < nr) { start[i] = base; base += cnt[q]; }
+            }
+            if (tid == 0) start[nr] = total;
+            __syncthreads();
+        }
+
+        // walk the items: every thread takes a contiguous share of all records' pixels / crossings / marker pixels
+        // (at least BM_MIN_SHARE of them: finding its place costs a thread more than a few items do)
+        {
+            const int ipt = max((total + BM_THREADS - 1) / BM_THREADS, BM_MIN_SHARE);
+            int j = tid * ipt;
+            const int jend = min(j + ipt, total);
+            if (j < jend) {
+                int e = bm_find(start, nr, j);
+                int k = j - start[e], n_items = start[e + 1] - start[e];
+                EdgeRec r = recs[e];
+                int L = (r.lin >> 28) ? (int)(r.lin & 0x1fffu) + 1 : 0;
+                // Bresenham state after k major steps: minor offset m, error term err (LineIterator's recurrence in closed form)
+                int dmaj = (int)(r.lin & 0x1fffu), dmin = (int)((r.lin >> 13) & 0x1fffu);
+                int m = (k > 0 && k < L) ? (2 * dmin * k + dmaj - 1) / (2 * dmaj) : 0;
+                int err = dmaj - 2 * dmin * (k + 1) + 2 * dmaj * m;
+                long long xr = r.x + (long long)(k > L ? k - L : 0) * r.dx;
+                for (; j < jend; j++, k++) {
+                    while (k >= n_items) {   // next record with at least one item
+                        e++;
+                        n_items = start[e + 1] - start[e];
+                        k = 0;
+                        if (n_items > 0) {
+                            r = recs[e];
+                            L = (r.lin >> 28) ? (int)(r.lin & 0x1fffu) + 1 : 0;
+                            dmaj = (int)(r.lin & 0x1fffu); dmin = (int)((r.lin >> 13) & 0x1fffu);
+                            m = 0; err = dmaj - 2 * dmin;
+                            xr = r.x;
+                        }
+                    }
+                    if (k < L) {
+                        const int x0 = (int)(r.xy0 & 0xffffu), y0 = (int)(r.xy0 >> 16);
+                        const int sy = (r.lin >> 26) & 1u ? -1 : 1;
+                        const bool vert = (r.lin >> 27) & 1u;
+                        const int x = vert ? x0 + m : x0 + k, y = vert ? y0 + sy * k : y0 + sy * m;
+                        bm_set(anyp, S, x, y);
+                        const int neg = err < 0;
+                        err += (neg ? 2 * dmaj : 0) - 2 * dmin;
+                        m += neg;
+                    } else if (mode == BM_FILL) {
+                        const int y = (int)(r.rows & 0xffffu) + (k - L);
+                        const long long X = xr >> BM_XY_SHIFT;
+                        xr += r.dx;
+                        if (X < 0) atomicXor(&carry[y >> 5], 1u << (y & 31));
+                        else if (X < cols) {
+                            atomicXor(&parp[__mul24(y, S) + (int)(X >> 5)], 1u << (X & 31));
+                            bm_set(anyp, S, (int)X, y);
+                        }
+                    } else {
+                        const int q = k - L;
+                        const int x = (int)(short)(r.mark & 0xffff) - 2 + q % 5, y = (r.mark >> 16) - 2 + q / 5;
+                        if ((unsigned)x < (unsigned)cols && (unsigned)y < (unsigned)rows) bm_set(anyp, S, x, y);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
     const int ch = a.channels;
     const size_t img_bytes = (size_t)rows * cols * ch;
     unsigned char *dst = a.out + (size_t)img * img_bytes;
     const unsigned cols2 = ((unsigned)a.bg & 255u) | ((unsigned)a.draw & 255u) << 8;
-    const bool use_tab = ch == 1 && (cols & 15) == 0 && (size_t)T * sizeof(EdgeRec) >= 256 * 8;
+    const bool use_tab = ch == 1 && (cols & 15) == 0; // (the layout reserves the table's 2 KB)
     uint2 *tab = reinterpret_cast<uint2 *>(recs); // (the records are dead from here on)
     if (use_tab && tid < 256) tab[tid] = make_uint2(bm_expand4((unsigned)tid & 15u, cols2), bm_expand4((unsigned)tid >> 4, cols2));
     if (use_tab && mode != BM_FILL) __syncthreads(); // (FILL: the barrier behind the parity pass)
 
-    if (mode == BM_FILL) {
+    if (mode == BM_FILL && !(F110_BM_X & 2)) {
         // ---- inside = crossing on the pixel, or an odd number of crossings strictly left of it; then the centre marker
         for (int y = tid; y < rows; y += BM_THREADS) {
             unsigned c = (carry[y >> 5] >> (y & 31)) & 1u;
             const bool marker_row = a.draw_center && y >= cy - 2 && y <= cy + 2;
             for (int w = 0; w < S; w++) {
                 unsigned p = parp[y * S + w];
+                // (a word column in which no row of this wave has a crossing, a carry or the marker: left as it is)
+                if (!__any((p | c) != 0u || marker_row)) continue;
                 p ^= p << 1; p ^= p << 2; p ^= p << 4; p ^= p << 8; p ^= p << 16; // inclusive prefix parity
                 unsigned v = anyp[y * S + w] | ((p << 1) ^ (0u - c));
                 c ^= p >> 31;
@@ -455,6 +563,16 @@ static __global__ __launch_bounds__(BM_THREADS) void bitmap_kernel(BitmapArgs a)
         const int dq = BM_THREADS / cpr, dr = BM_THREADS - dq * cpr; // (y, h) advanced by carry: see below
         int y = tid / cpr, h = tid - y * cpr, yS = __mul24(y, S);
         const int dqS = __mul24(dq, S);
+        if (dr == 0) {
+            // (the threads of a workgroup cover whole rows, e.g. 256 columns: a thread stays in its column of chunks)
+            const unsigned *src = anyp + yS + (h >> 1);
+            const unsigned sh = (h & 1) * 16;
+            for (int c = tid; c < chunks; c += BM_THREADS, src += dqS) {
+                const unsigned bits = *src >> sh;
+                const uint2 lo = tab[bits & 0xffu], hi = tab[(bits >> 8) & 0xffu];
+                bm_store16<true>(dst4 + c, lo.x, lo.y, hi.x, hi.y);
+            }
+        } else
         for (int c = tid; c < chunks; c += BM_THREADS) {
             const unsigned bits = anyp[yS + (h >> 1)] >> ((h & 1) * 16);
             const uint2 lo = tab[bits & 0xffu], hi = tab[(bits >> 8) & 0xffu];

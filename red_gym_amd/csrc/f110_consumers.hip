@@ -237,7 +237,7 @@ extern "C" int f110_bitmap_create(const f110_bitmap_config *cfg, const int32_t *
         if (indices[k] < 0 || indices[k] >= cfg->num_beams) return fail(F110_E_INDEX, "beam index %d out of range", indices[k]);
     int S = (cfg->cols + 31) / 32;
     S |= 1; // odd row pitch: the per-row parity pass is LDS-bank-conflict free
-    const size_t lds = bitmap_lds_bytes(T, cfg->rows, S);
+    const size_t lds = bitmap_lds_bytes(T, cfg->rows, S, cfg->draw_mode);
     if (lds > 150 * 1024) return fail(F110_E_INVALID, "image %dx%d with %d beams needs %zu bytes of LDS (limit 150 KiB)", cfg->rows, cfg->cols, T, lds);
     f110_bitmap *b = new (std::nothrow) f110_bitmap;
     if (!b) return fail(F110_E_INVALID, "out of memory");
@@ -271,7 +271,7 @@ extern "C" int f110_bitmap_render(f110_bitmap *b, const void *scans, int32_t sca
     a.idx = b->d_idx; a.cosv = b->d_cos; a.sinv = b->d_sin; a.T = b->cfg.target_beam_count;
     a.rows = b->cfg.rows; a.cols = b->cfg.cols; a.channels = b->cfg.channels; a.mode = b->cfg.draw_mode;
     a.bg = b->cfg.bg_value; a.draw = b->cfg.draw_value; a.draw_center = b->cfg.draw_center;
-    a.scale = b->cfg.scaling_factor; a.out = out; a.S = b->S;
+    a.scale = b->cfg.scaling_factor; a.out = out; a.S = b->S; a.qcap = bm_queue_cap(a.T, a.mode);
     hipLaunchKernelGGL(bitmap_kernel, dim3((unsigned)n), dim3(BM_THREADS), b->lds, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return F110_OK;
