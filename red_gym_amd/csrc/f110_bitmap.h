@@ -29,6 +29,12 @@ constexpr int BM_THREADS = F110_BM_THREADS;
 constexpr int BM_MAX_T = 2048;
 constexpr int BM_PER_MAX = (BM_MAX_T + BM_THREADS - 1) / BM_THREADS;
 constexpr int BM_XY_SHIFT = 16;
+constexpr int BM_TL = 10;
+#if defined(F110_BM_TIMELINE)
+#define BM_STAMP(i) do { if (tid == 0) s_tl[i] = wall_clock64(); } while (0)
+#else
+#define BM_STAMP(i) do { } while (0)
+#endif
 
 struct BitmapArgs {
     const void *scans;       // [n, stride] f32 or f64
@@ -43,6 +49,7 @@ struct BitmapArgs {
     unsigned char *out;      // [n, rows, cols(, channels)]
     int S;                   // words per bit-plane row (cols/32 rounded up, made odd)
     int qcap;                // segment records held in LDS at a time (bm_queue_cap)
+    unsigned long long *tl;  // diagnostics (-DF110_BM_TIMELINE): [n][BM_TL] clock stamps of thread 0 at the stage boundaries
 };
 
 // One segment / polygon edge, ready to be walked item by item (32 bytes, two ds_read_b128):
@@ -77,8 +84,11 @@ constexpr int BM_MIN_SHARE = F110_BM_MIN_SHARE; // items per thread of the recor
 //   any   u32[rows*S]     the 1-bit image
 //   queue u16[T]          queued segments: inside the image from the front, needing clipLine from the back
 //   start int[qcap+1]     exclusive prefix of the round's item counts
-struct BmLayout { unsigned recs, pts, par, any, queue, start, bytes; };
-__host__ __device__ inline BmLayout bm_layout(int T, int rows, int S, int qcap, int mode)
+//   beams u16[T]          the beam of every point (BitmapArgs::idx, staged once per workgroup)
+//   cs    double2[T]      cos / sin of every point's drawing angle (staged once per workgroup)
+//   stage u32[2][1 or 2][T64]  the ranges of the next two images as loaded (low words; for an fp64 scan also the high words), T64 = T rounded up to 64
+struct BmLayout { unsigned recs, pts, par, any, queue, start, beams, cs, stage, bytes; };
+__host__ __device__ inline BmLayout bm_layout(int T, int rows, int S, int qcap, int mode, int f64, bool ahead)
 {
     BmLayout l;
     auto up = [](unsigned v) { return (v + 15u) & ~15u; };
@@ -88,19 +98,31 @@ __host__ __device__ inline BmLayout bm_layout(int T, int rows, int S, int qcap, 
     l.any = up(l.par + (mode == BM_FILL ? ((unsigned)rows * S + (unsigned)((rows + 31) / 32)) * 4u : 0u));
     l.queue = up(l.any + (unsigned)rows * S * 4u);
     l.start = up(l.queue + (unsigned)T * 2u);
-    l.bytes = up(l.start + (unsigned)(qcap + 1) * 4u);
+    l.beams = up(l.start + (unsigned)(qcap + 1) * 4u);
+    l.cs = up(l.beams + (ahead ? (unsigned)T * 2u : 0u));
+    l.stage = up(l.cs + (ahead ? (unsigned)T * 16u : 0u));
+    l.bytes = up(l.stage + (ahead ? (f64 ? 4u : 2u) * (((unsigned)T + 63u) & ~63u) * 4u : 0u));
     return l;
 }
-// Records per round.  RAYS queues every segment (centre -> point, plus its marker); FILL / POLYGON queue only what the
-// direct pass leaves: long edges and the ones that need clipLine -- a few per cent on a lidar polygon.  More queued
-// segments than records are drawn in several rounds (drawing is OR / XOR into the planes: any order, any grouping).
+// Two shapes of the kernel (bm_fetch_ahead):
+//   FILL / POLYGON -- bound by the write and by the latency of a workgroup's stages: ranges fetched two images ahead into
+//     LDS (beams / cs / stage above), 64 records per round (the direct pass leaves ~33 of a lidar polygon's 600 edges: long
+//     ones and the ones that need clipLine), registers budgeted for 6 waves per SIMD (three workgroups per CU);
+//   RAYS -- 50 000 ray and marker pixels per image, bound by VALU / LDS-atomic issue: as many waves as possible, i.e. no
+//     staging buffers (<= 40 KB of LDS: four workgroups per CU, 8 waves per SIMD), every ray's record in one round, the
+//     ranges loaded where they are used (their latency is a tenth of an image's drawing time).
+// More queued segments than records are drawn in several rounds (drawing is OR / XOR into the planes: any order, any grouping).
+//   (four-channel images, 256 KB each, are bound by the write alone: measured 4 % better in the second shape)
+__host__ __device__ inline bool bm_fetch_ahead(int mode, int channels) { return mode != BM_RAYS && channels != 4; }
 __host__ __device__ inline int bm_queue_cap(int T, int mode)
 {
-    if (mode == BM_RAYS) return T;
-    const int c = (T + 3) / 4 < 128 ? 128 : (T + 3) / 4;
-    return c < T ? c : T;
+    return mode == BM_RAYS || T < 64 ? T : 64;
 }
-__host__ __device__ inline size_t bitmap_lds_bytes(int T, int rows, int S, int mode) { return bm_layout(T, rows, S, bm_queue_cap(T, mode), mode).bytes; }
+__host__ __device__ inline int bm_waves_per_eu(size_t lds_bytes) { return lds_bytes + 512 <= 40 * 1024 ? 8 : 6; }
+__host__ __device__ inline size_t bitmap_lds_bytes(int T, int rows, int S, int mode, int channels, int f64)
+{
+    return bm_layout(T, rows, S, bm_queue_cap(T, mode), mode, f64, bm_fetch_ahead(mode, channels)).bytes;
+}
 
 // cv::clipLine(Size2l, Point2l&, Point2l&), drawing.cpp
 __device__ inline bool bm_clip_line(long long width, long long height, long long &x1, long long &y1, long long &x2, long long &y2)
@@ -227,6 +249,15 @@ __device__ inline int bm_edge_setup_inside(int mode, int2 p0, int2 p1, EdgeRec &
     return L + R;
 }
 
+// Workgroup barrier for data exchanged through LDS only.  __syncthreads() also waits for every global load and store of the
+// wave (s_waitcnt vmcnt(0)); in this kernel that would drain the previous image's streamed-out pixels and the prefetched
+// ranges at every stage boundary.  Global memory carries nothing between the threads here: inputs are read-only, the image
+// is write-only.
+__device__ inline void bm_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 __device__ inline void bm_set(unsigned *plane, int S, int x, int y) { atomicOr(&plane[__mul24(y, S) + (x >> 5)], 1u << (x & 31)); }
 
 // block-wide exclusive scan of one int per thread; returns the exclusive prefix, the sum in `total`
@@ -239,7 +270,7 @@ __device__ inline int bm_block_scan(int v, int &total, int *s_wave)
         if (lane >= off) incl += t;
     }
     if (lane == 63) s_wave[wave] = incl;
-    __syncthreads();
+    bm_barrier();
     int base = 0, tot = 0;
     for (int w = 0; w < BM_THREADS / 64; w++) {
         const int t = s_wave[w];
@@ -285,13 +316,68 @@ __device__ inline unsigned bm_expand4(unsigned nib, unsigned cols2)
 
 // lidar.py:70-73: point k of image img = rint(center + (scaling_factor * data[k]) * {cos, sin}(angle k)).astype(int),
 // data = scan[indices] (:63-64); the integers the reference hands to cv2.fillPoly / polylines / line.
+__device__ inline double bm_range(const BitmapArgs &a, int img, int beam)
+{
+    const long long o = (long long)img * a.stride + beam;
+    return a.is_f64 ? static_cast<const double *>(a.scans)[o] : (double)static_cast<const float *>(a.scans)[o];
+}
+// ---- the ranges of an image, fetched ahead of time straight into LDS (global_load_lds_dword: no register holds them)
+// by the UPPER half of the workgroup's threads: issuer thread u = tid - BM_THREADS/2 fetches points u, u + BM_THREADS/2, ...
+// Returns the number of loads THIS WAVE issued (wave-uniform): the caller waits with s_waitcnt vmcnt(that number) to know
+// that everything issued BEFORE them -- the previous prefetch -- has landed.
+// (Written as inline assembly, not __builtin_amdgcn_global_load_lds: the compiler would guard every later LDS read of the
+// wave with s_waitcnt vmcnt(0) -- also the reads of the store loop, between the stores.  The waits are bm_wait_vm's.)
+__device__ inline void bm_load_to_lds(const unsigned *src, const unsigned *lds_dst_wave /* the wave's lane 0 slot; uniform */)
+{
+    const unsigned m0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_dst_wave); // low word of a flat LDS address = LDS offset
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" : : "v"(src), "s"(m0) : "memory", "m0");
+}
+__device__ inline int bm_prefetch(const BitmapArgs &a, int img, const unsigned short *beams, unsigned *stage, int tid)
+{
+    constexpr int HALF = BM_THREADS / 2;
+    const int T = a.T, T64 = (T + 63) & ~63;
+    const int u = tid - HALF, k0 = u & ~63; // (k0: the wave's first point of a pass, wave-uniform)
+    int issued = 0;
+    if (u < 0) return 0;
+    for (int j = 0; k0 + j * HALF < T; j++) {
+        const int k = u + j * HALF, base = __builtin_amdgcn_readfirstlane(k0 + j * HALF);
+        if (k < T) {
+            const long long o = (long long)img * a.stride + beams[k];
+            if (a.is_f64) {
+                const unsigned *src = reinterpret_cast<const unsigned *>(static_cast<const double *>(a.scans) + o);
+                bm_load_to_lds(src, stage + base);
+                bm_load_to_lds(src + 1, stage + T64 + base);
+            } else {
+                bm_load_to_lds(static_cast<const unsigned *>(a.scans) + o, stage + base);
+            }
+        }
+        issued += a.is_f64 ? 2 : 1;
+    }
+    return issued;
+}
+// s_waitcnt vmcnt(n) for a run-time n <= 16 (the counter's immediate)
+__device__ inline void bm_wait_vm(int n)
+{
+    switch (n) {
+#define BM_W(i) case i: asm volatile("s_waitcnt vmcnt(" #i ")" ::: "memory"); break;
+    BM_W(1) BM_W(2) BM_W(3) BM_W(4) BM_W(5) BM_W(6) BM_W(7) BM_W(8) BM_W(9) BM_W(10) BM_W(11) BM_W(12) BM_W(13) BM_W(14) BM_W(15) BM_W(16)
+#undef BM_W
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+__device__ inline double bm_staged_range(const BitmapArgs &a, const unsigned *stage, int k)
+{
+    const int T64 = (a.T + 63) & ~63;
+    return a.is_f64 ? __hiloint2double((int)stage[T64 + k], (int)stage[k]) : (double)__uint_as_float(stage[k]);
+}
+__device__ inline int2 bm_point_at(double scale, double r, double c, double s, int cx, int cy)
+{
+    const double d = scale * r;
+    return make_int2((int)(long long)__builtin_rint((double)cx + d * c), (int)(long long)__builtin_rint((double)cy + d * s));
+}
 __device__ inline int2 bm_point(const BitmapArgs &a, int img, int k, int cx, int cy)
 {
-    const long long o = (long long)img * a.stride + a.idx[k];
-    const double r = a.is_f64 ? static_cast<const double *>(a.scans)[o] : (double)static_cast<const float *>(a.scans)[o];
-    const double d = a.scale * r;
-    return make_int2((int)(long long)__builtin_rint((double)cx + d * a.cosv[k]),
-                     (int)(long long)__builtin_rint((double)cy + d * a.sinv[k]));
+    return bm_point_at(a.scale, bm_range(a, img, a.idx[k]), a.cosv[k], a.sinv[k], cx, cy);
 }
 
 // function-level view of the point stage (f110_bitmap_points): out [n, T, 2] int32 (x, y)
@@ -308,7 +394,9 @@ static __global__ __launch_bounds__(256) void bitmap_points_kernel(BitmapArgs a,
 #endif
 
 #if defined(F110_UNIT_CONSUMERS)
-static __global__ __launch_bounds__(BM_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void bitmap_kernel(BitmapArgs a)
+// WPE: waves per SIMD the registers are budgeted for; AHEAD: ranges fetched two images ahead (see bm_fetch_ahead)
+template <int WPE, bool AHEAD>
+static __global__ __launch_bounds__(BM_THREADS) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void bitmap_kernel(BitmapArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     __shared__ int s_wave[BM_THREADS / 64];
@@ -317,9 +405,9 @@ static __global__ __launch_bounds__(BM_THREADS) __attribute__((amdgpu_waves_per_
     // int64 division truncates toward zero is sign * this; a table look-up instead of an fp64 division per edge
     __shared__ int s_fdx[64];
     static_assert(BM_DIRECT <= 8, "s_fdx holds the increments of edges of at most 8 items");
-    const int T = a.T, rows = a.rows, cols = a.cols, S = a.S, tid = threadIdx.x, mode = a.mode, qcap = a.qcap;
-    const int lane = tid & 63;
-    const BmLayout lay = bm_layout(T, rows, S, qcap, mode);
+    const int T = a.T, rows = a.rows, cols = a.cols, S = a.S, tid0 = threadIdx.x, mode = a.mode, qcap = a.qcap;
+    const int lane = tid0 & 63;
+    const BmLayout lay = bm_layout(T, rows, S, qcap, mode, a.is_f64, AHEAD);
     EdgeRec *recs = reinterpret_cast<EdgeRec *>(s_raw + lay.recs);
     int2 *pts = reinterpret_cast<int2 *>(s_raw + lay.pts);
     unsigned *parp = reinterpret_cast<unsigned *>(s_raw + lay.par);
@@ -327,12 +415,56 @@ static __global__ __launch_bounds__(BM_THREADS) __attribute__((amdgpu_waves_per_
     unsigned *anyp = reinterpret_cast<unsigned *>(s_raw + lay.any);
     unsigned short *queue = reinterpret_cast<unsigned short *>(s_raw + lay.queue);
     int *start = reinterpret_cast<int *>(s_raw + lay.start);
+    unsigned short *beams = reinterpret_cast<unsigned short *>(s_raw + lay.beams);
+    double2 *cs = reinterpret_cast<double2 *>(s_raw + lay.cs);
+    unsigned *stage = reinterpret_cast<unsigned *>(s_raw + lay.stage);
+    const int stage_words = (a.is_f64 ? 2 : 1) * ((T + 63) & ~63); // of one of the two buffers
 
-    const int img = blockIdx.x;
+#if defined(F110_BM_TIMELINE)
+    __shared__ unsigned long long s_tl[BM_TL];
+#endif
     const int cx = rows / 2, cy = cols / 2; // lidar.py:75: center = (dims[0]//2, dims[1]//2), used as (x, y)
+    if (tid0 < 64) s_fdx[tid0] = (tid0 & 7) ? ((tid0 >> 3) << BM_XY_SHIFT) / (tid0 & 7) : 0;
 
+    // A workgroup draws images blockIdx.x, blockIdx.x + gridDim.x, ... (the launch holds as many workgroups as the GPU runs
+    // at once).  What an image needs from memory -- its T ranges, an HBM gather -- is fetched TWO images ahead, into LDS:
+    // with one image per workgroup 6 of a workgroup's 15 us went into waiting for these loads, and merely ISSUING them
+    // stalls a wave for ~1.7 us while every CU's memory pipe is full of the other images' pixels.  So the loads are issued
+    // by the upper half of the waves while the lower half runs the parity pass, and consumed an image later
+    // (profiles/r05_bitmap.txt).
     // lidar.py:70-81: points = rint(center + (scaling_factor * data) * {cos, sin}(angles)).astype(int)
-    for (int k = tid; k < ((F110_BM_X & 4) ? 0 : T); k += BM_THREADS) pts[k] = bm_point(a, img, k, cx, cy);
+    if (AHEAD) {
+#pragma unroll
+        for (int q = 0; q < BM_PER_MAX; q++) {
+            const int k = tid0 + q * BM_THREADS;
+            if (k < T) {
+                const int b = a.idx[k];
+                const double2 c = make_double2(a.cosv[k], a.sinv[k]);
+                beams[k] = (unsigned short)b;
+                cs[k] = c;
+                if ((int)blockIdx.x < a.n && !(F110_BM_X & 4)) pts[k] = bm_point_at(a.scale, bm_range(a, blockIdx.x, b), c.x, c.y, cx, cy);
+            }
+        }
+        bm_barrier(); // (beams staged)
+        if ((int)(blockIdx.x + gridDim.x) < a.n && !(F110_BM_X & 4)) (void)bm_prefetch(a, blockIdx.x + gridDim.x, beams, stage + stage_words, tid0);
+    }
+    int it = 0;
+    // (!AHEAD: one image per workgroup, the launch has a workgroup per image -- the loop is left after one pass, and the
+    // compiler, seeing that, keeps nothing in registers around it.  The grid never exceeds the image count.)
+    int img = blockIdx.x;
+    do {
+    // (the thread index re-enters every image through an opaque copy: per-thread addresses of the stages below are
+    // then recomputed per image instead of being carried in registers around the whole loop -- the kernel has 64)
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));
+#if defined(F110_BM_TIMELINE)
+    if (tid < BM_TL) s_tl[tid] = 0;
+    bm_barrier();
+#endif
+    BM_STAMP(0);
+    const int img_next = img + (int)gridDim.x, img_next2 = img_next + (int)gridDim.x;
+    if (!AHEAD)
+        for (int k = tid; k < ((F110_BM_X & 4) ? 0 : T); k += BM_THREADS) pts[k] = bm_point(a, img, k, cx, cy);
     // zero both planes (contiguous, each on a 16-byte boundary: 16 bytes per store)
     {
         uint4 *z4 = reinterpret_cast<uint4 *>(parp);
@@ -340,8 +472,8 @@ static __global__ __launch_bounds__(BM_THREADS) __attribute__((amdgpu_waves_per_
         for (int i = tid; i < n4; i += BM_THREADS) z4[i] = make_uint4(0u, 0u, 0u, 0u);
     }
     if (tid < 2) s_nq[tid] = 0;
-    if (tid < 64) s_fdx[tid] = (tid & 7) ? ((tid >> 3) << BM_XY_SHIFT) / (tid & 7) : 0;
-    __syncthreads();
+    bm_barrier();
+    BM_STAMP(1); // planes zeroed (the points were made before the previous image's stores)
     if (a.draw_center && mode != BM_FILL && tid < 25) {
         // lidar.py:98-100: centre marker in the draw colour (FILL clears it after the fill, below)
         const int x = cx - 2 + tid % 5, y = cy - 2 + tid / 5;
@@ -408,8 +540,16 @@ static __global__ __launch_bounds__(BM_THREADS) __attribute__((amdgpu_waves_per_
             }
         }
     }
-    __syncthreads();
+    bm_barrier();
 
+    BM_STAMP(2); // direct pass done
+    // ---- the ranges of the image after the next, into the buffer the previous image's were read from, issued by the
+    // upper waves, which have nothing to do while the first waves set the records up; then wait for the loads issued
+    // an image ago (everything but the ones just issued)
+    if (AHEAD && tid >= BM_THREADS / 2) {
+        const int issued = (img_next2 < a.n && !(F110_BM_X & 4)) ? bm_prefetch(a, img_next2, beams, stage + (it & 1) * stage_words, tid) : 0;
+        bm_wait_vm(issued);
+    }
     // ---- record path: rounds of at most qcap queued segments -- records, prefix of their item counts, item walk
     const int n_in = s_nq[0], nq = n_in + s_nq[1];
     for (int q0 = 0; q0 < nq; q0 += qcap) {
@@ -418,7 +558,8 @@ static __global__ __launch_bounds__(BM_THREADS) __attribute__((amdgpu_waves_per_
         // fp64 divisions the long one -- in separate loops, so that a wave runs the long form only if it holds such a segment
         for (int pass = 0; pass < 2; pass++) {
             const int j0 = pass == 0 ? q0 : max(q0, n_in), j1 = pass == 0 ? min(q0 + nr, n_in) : q0 + nr;
-            for (int j = j0 + tid; j < j1; j += BM_THREADS) {
+            const int t2 = (tid - pass * 64) & (BM_THREADS - 1); // (the two forms start on different waves: side by side)
+            for (int j = j0 + t2; j < j1; j += BM_THREADS) {
                 const int i = pass == 0 ? queue[j] : queue[T - 1 - (j - n_in)];
                 const int2 p1 = pts[i];
                 const int2 p0 = mode == BM_RAYS ? make_int2(cx, cy) : pts[i == 0 ? T - 1 : i - 1];
@@ -427,7 +568,8 @@ static __global__ __launch_bounds__(BM_THREADS) __attribute__((amdgpu_waves_per_
                 recs[j - q0] = r;
             }
         }
-        __syncthreads();
+        bm_barrier();
+        BM_STAMP(3); // records
         // exclusive prefix of the item counts, in place
         int total;
         if (nr <= 64) {
@@ -442,7 +584,7 @@ static __global__ __launch_bounds__(BM_THREADS) __attribute__((amdgpu_waves_per_
                 if (tid < nr) start[tid] = incl - v;
                 if (tid == 63) start[nr] = incl;
             }
-            __syncthreads();
+            bm_barrier();
             total = start[nr];
         } else {
             // thread t owns records t*per .. t*per + per - 1
@@ -461,9 +603,10 @@ static __global__ __launch_bounds__(BM_THREADS) __attribute__((amdgpu_waves_per_
                 if (q < per && i < nr) { start[i] = base; base += cnt[q]; }
             }
             if (tid == 0) start[nr] = total;
-            __syncthreads();
+            bm_barrier();
         }
 
+        BM_STAMP(4); // prefix
         // walk the items: every thread takes a contiguous share of all records' pixels / crossings / marker pixels
         // (at least BM_MIN_SHARE of them: finding its place costs a thread more than a few items do)
         {
@@ -519,9 +662,10 @@ static __global__ __launch_bounds__(BM_THREADS) __attribute__((amdgpu_waves_per_
                 }
             }
         }
-        __syncthreads();
+        bm_barrier();
     }
 
+    BM_STAMP(5); // walk
     const int ch = a.channels;
     const size_t img_bytes = (size_t)rows * cols * ch;
     unsigned char *dst = a.out + (size_t)img * img_bytes;
@@ -529,14 +673,23 @@ static __global__ __launch_bounds__(BM_THREADS) __attribute__((amdgpu_waves_per_
     const bool use_tab = ch == 1 && (cols & 15) == 0; // (the layout reserves the table's 2 KB)
     uint2 *tab = reinterpret_cast<uint2 *>(recs); // (the records are dead from here on)
     if (use_tab && tid < 256) tab[tid] = make_uint2(bm_expand4((unsigned)tid & 15u, cols2), bm_expand4((unsigned)tid >> 4, cols2));
-    if (use_tab && mode != BM_FILL) __syncthreads(); // (FILL: the barrier behind the parity pass)
-
     if (mode == BM_FILL && !(F110_BM_X & 2)) {
         // ---- inside = crossing on the pixel, or an odd number of crossings strictly left of it; then the centre marker
-        for (int y = tid; y < rows; y += BM_THREADS) {
+        // (a row per thread; with rows for half of the threads only, two threads per row: the second takes the words from
+        // S0 on, its carry = the row's carry bit ^ the parity of the crossings in the words before)
+        const bool halves = 2 * rows <= BM_THREADS;
+        const int S0 = halves ? (S + 1) / 2 : S;
+        for (int yy = tid; yy < (halves ? 2 * rows : rows); yy += BM_THREADS) {
+            const bool second = halves && yy >= rows;
+            const int y = second ? yy - rows : yy;
             unsigned c = (carry[y >> 5] >> (y & 31)) & 1u;
+            if (second) {
+                unsigned x = 0;
+                for (int w = 0; w < S0; w++) x ^= parp[y * S + w];
+                c ^= (unsigned)__popc(x) & 1u;
+            }
             const bool marker_row = a.draw_center && y >= cy - 2 && y <= cy + 2;
-            for (int w = 0; w < S; w++) {
+            for (int w = second ? S0 : 0; w < (second ? S : S0); w++) {
                 unsigned p = parp[y * S + w];
                 // (a word column in which no row of this wave has a crossing, a carry or the marker: left as it is)
                 if (!__any((p | c) != 0u || marker_row)) continue;
@@ -550,9 +703,20 @@ static __global__ __launch_bounds__(BM_THREADS) __attribute__((amdgpu_waves_per_
                 anyp[y * S + w] = v;
             }
         }
-        __syncthreads();
     }
+    bm_barrier();
 
+    BM_STAMP(6); // parity
+    // ---- the next image's points (this image's are dead since the last record round; no store of this image is in
+    // flight yet, so waiting for the ranges waits for nothing else)
+    if (AHEAD && img_next < a.n) {
+#pragma unroll
+        for (int q = 0; q < BM_PER_MAX; q++) {
+            const int k = tid + q * BM_THREADS;
+            if (k < T && !(F110_BM_X & 4)) { const double2 c = cs[k]; pts[k] = bm_point_at(a.scale, bm_staged_range(a, stage + ((it + 1) & 1) * stage_words, k), c.x, c.y, cx, cy); }
+        }
+    }
+    BM_STAMP(8); // next points
     // ---- stream the image out: grey levels and channels are expanded here (the only HBM write)
     // One channel: 8 pixel bits -> 8 grey bytes through a 256-entry table (2 KB, in the segment records' place: they are
     // dead after the walk), built by the first 256 threads.  Two ds_read_b64 per 16-byte store replace the twelve VALU
@@ -632,6 +796,15 @@ static __global__ __launch_bounds__(BM_THREADS) __attribute__((amdgpu_waves_per_
             dst[o] = c == 3 ? (unsigned char)255 : (unsigned char)(bit ? a.draw : a.bg);
         }
     }
+#if defined(F110_BM_TIMELINE)
+    bm_barrier();
+    BM_STAMP(7); // stores issued
+    if (tid == 0 && a.tl) for (int i = 0; i < BM_TL; i++) a.tl[(size_t)img * BM_TL + i] = s_tl[i];
+#endif
+    if (!AHEAD) break;
+    bm_barrier(); // the planes, the records' place (grey-level table) and the points are the next image's from here
+    img += (int)gridDim.x; it++;
+    } while (img < a.n);
 }
 #endif
 

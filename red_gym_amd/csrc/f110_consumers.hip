@@ -203,12 +203,19 @@ extern "C" int f110_pure_pursuit_tracks(f110_handle *h, const double *waypoints,
 }
 
 // ---------------------------------------------------------------- scan -> bitmap
+static const void *bitmap_fn(size_t lds, int mode, int channels)
+{
+    if (bm_fetch_ahead(mode, channels)) return (const void *)&bitmap_kernel<6, true>; // (its LDS leaves room for three workgroups per CU at most)
+    return bm_waves_per_eu(lds) == 8 ? (const void *)&bitmap_kernel<8, false> : (const void *)&bitmap_kernel<6, false>;
+}
+
 struct f110_bitmap {
     f110_bitmap_config cfg;
     int32_t *d_idx = nullptr;
     double *d_cos = nullptr, *d_sin = nullptr;
     int S = 0;
-    size_t lds = 0;
+    size_t lds[2] = {0, 0};  // dynamic LDS of a launch on fp32 / fp64 scans (the ranges' staging buffers differ)
+    int resident[2] = {0, 0}; // workgroups of bitmap_kernel the device runs at once (the launch's grid: a workgroup loops over images)
 };
 
 extern "C" void f110_bitmap_destroy(f110_bitmap *b)
@@ -229,6 +236,7 @@ extern "C" int f110_bitmap_create(const f110_bitmap_config *cfg, const int32_t *
     // the reference's assertions (lidar.py:50-56)
     if (!(T > 0 && T < cfg->num_beams)) return fail(F110_E_INVALID, "target_beam_count must satisfy 0 < %d < len(scan) = %d", T, cfg->num_beams);
     if (T > 2048) return fail(F110_E_INVALID, "target_beam_count %d > 2048", T);
+    if (cfg->num_beams > 65536) return fail(F110_E_INVALID, "scans of more than 65536 beams are not supported (%d)", cfg->num_beams);
     if (cfg->rows <= 0 || cfg->cols <= 0) return fail(F110_E_INVALID, "output_image_dims must be at least 1x1");
     if (cfg->rows > 4096 || cfg->cols > 4096) return fail(F110_E_INVALID, "output_image_dims above 4096 are not supported");
     if (cfg->channels != 1 && cfg->channels != 3 && cfg->channels != 4) return fail(F110_E_INVALID, "channels must 1, 3, or 4");
@@ -237,11 +245,11 @@ extern "C" int f110_bitmap_create(const f110_bitmap_config *cfg, const int32_t *
         if (indices[k] < 0 || indices[k] >= cfg->num_beams) return fail(F110_E_INDEX, "beam index %d out of range", indices[k]);
     int S = (cfg->cols + 31) / 32;
     S |= 1; // odd row pitch: the per-row parity pass is LDS-bank-conflict free
-    const size_t lds = bitmap_lds_bytes(T, cfg->rows, S, cfg->draw_mode);
+    const size_t lds = bitmap_lds_bytes(T, cfg->rows, S, cfg->draw_mode, cfg->channels, 1); // (fp64 scans: the larger of the two layouts)
     if (lds > 150 * 1024) return fail(F110_E_INVALID, "image %dx%d with %d beams needs %zu bytes of LDS (limit 150 KiB)", cfg->rows, cfg->cols, T, lds);
     f110_bitmap *b = new (std::nothrow) f110_bitmap;
     if (!b) return fail(F110_E_INVALID, "out of memory");
-    b->cfg = *cfg; b->S = S; b->lds = lds;
+    b->cfg = *cfg; b->S = S; b->lds[1] = lds; b->lds[0] = bitmap_lds_bytes(T, cfg->rows, S, cfg->draw_mode, cfg->channels, 0);
     DeviceScope on_dev(cfg->device);
     if (on_dev.err != hipSuccess) { delete b; return fail(F110_E_HIP, "hipSetDevice(%d) failed", cfg->device); }
     hipError_t e = hipMalloc((void **)&b->d_idx, T * sizeof(int32_t));
@@ -251,7 +259,18 @@ extern "C" int f110_bitmap_create(const f110_bitmap_config *cfg, const int32_t *
     if (e == hipSuccess) e = hipMemcpy(b->d_cos, cosines, T * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(b->d_sin, sines, T * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess && lds > 64 * 1024)
-        e = hipFuncSetAttribute((const void *)bitmap_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = hipFuncSetAttribute(bitmap_fn(lds, cfg->draw_mode, cfg->channels), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        e = hipGetDevice(&dev);
+        if (e == hipSuccess) e = hipGetDeviceProperties(&prop, dev);
+        for (int f = 0; f < 2 && e == hipSuccess; f++) {
+            int per_cu = 0;
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bitmap_fn(b->lds[f], cfg->draw_mode, cfg->channels), BM_THREADS, b->lds[f]);
+            b->resident[f] = std::max(1, per_cu) * std::max(1, prop.multiProcessorCount);
+        }
+    }
     if (e != hipSuccess) { f110_bitmap_destroy(b); return fail(F110_E_HIP, "f110_bitmap_create: %s", hipGetErrorString(e)); }
     *out = b;
     return F110_OK;
@@ -271,9 +290,38 @@ extern "C" int f110_bitmap_render(f110_bitmap *b, const void *scans, int32_t sca
     a.idx = b->d_idx; a.cosv = b->d_cos; a.sinv = b->d_sin; a.T = b->cfg.target_beam_count;
     a.rows = b->cfg.rows; a.cols = b->cfg.cols; a.channels = b->cfg.channels; a.mode = b->cfg.draw_mode;
     a.bg = b->cfg.bg_value; a.draw = b->cfg.draw_value; a.draw_center = b->cfg.draw_center;
-    a.scale = b->cfg.scaling_factor; a.out = out; a.S = b->S; a.qcap = bm_queue_cap(a.T, a.mode);
-    hipLaunchKernelGGL(bitmap_kernel, dim3((unsigned)n), dim3(BM_THREADS), b->lds, (hipStream_t)stream, a);
+    a.scale = b->cfg.scaling_factor; a.out = out; a.S = b->S; a.qcap = bm_queue_cap(a.T, a.mode); a.tl = nullptr;
+#if defined(F110_BM_TIMELINE)
+    // diagnostics build only: every launch is followed by a synchronisation and a table of the stage times on stderr
+    static unsigned long long *tl = nullptr; static size_t tl_n = 0;
+    if (tl_n < (size_t)n) { if (tl) (void)hipFree(tl); HIP_TRY(hipMalloc((void **)&tl, (size_t)n * BM_TL * 8)); tl_n = (size_t)n; }
+    a.tl = tl;
+#endif
+    const char *grid_env = getenv("F110_BM_GRID"); // sweeps and tests only: workgroups of the launch (read per call)
+    // fetch-ahead shape: as many workgroups as the device runs at once, each looping over images; else one per image
+    const int64_t grid = !bm_fetch_ahead(a.mode, a.channels) ? n : std::min<int64_t>(n, grid_env && atoi(grid_env) > 0 ? atoi(grid_env) : b->resident[a.is_f64]);
+    void *params[1] = {(void *)&a};
+    HIP_TRY(hipLaunchKernel(bitmap_fn(b->lds[a.is_f64], a.mode, a.channels), dim3((unsigned)grid), dim3(BM_THREADS), params, b->lds[a.is_f64], (hipStream_t)stream));
     HIP_TRY(hipGetLastError());
+#if defined(F110_BM_TIMELINE)
+    {
+        HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+        std::vector<unsigned long long> h((size_t)n * BM_TL);
+        HIP_TRY(hipMemcpy(h.data(), tl, h.size() * 8, hipMemcpyDeviceToHost));
+        static const char *names[] = {"zero", "direct pass", "records", "prefix", "walk", "parity", "next points", "store issue"};
+        double sum[8] = {0}; unsigned long long t0 = ~0ull, t1 = 0;
+        for (int64_t i = 0; i < n; i++) {
+            const unsigned long long *s = &h[(size_t)i * BM_TL];
+            unsigned long long prev = s[0];
+            static const int order[8] = {1, 2, 3, 4, 5, 6, 8, 7};
+            for (int j = 0; j < 8; j++) { const int k = order[j]; if (s[k]) { sum[j] += (double)(s[k] - prev); prev = s[k]; } }
+            t0 = std::min(t0, s[0]); t1 = std::max(t1, s[7]);
+        }
+        fprintf(stderr, "bitmap timeline (%lld images, 100 MHz ticks -> us): launch %.1f us;", (long long)n, (t1 - t0) / 100.0);
+        for (int j = 0; j < 8; j++) fprintf(stderr, " %s %.2f", names[j], sum[j] / n / 100.0);
+        fprintf(stderr, "\n");
+    }
+#endif
     return F110_OK;
 }
 

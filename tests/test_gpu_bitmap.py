@@ -126,6 +126,36 @@ def test_scan_occupancy_matches_oracle_and_dataset_shape():
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize('mode,T,dims', [('FILL', 600, (256, 256)), ('FILL', 1079, (256, 256)), ('FILL', 2047, (512, 320)),
+                                         ('POLYGON', 600, (256, 256)), ('RAYS', 50, (256, 256)), ('FILL', 100, (97, 61))])
+def test_workgroups_that_draw_many_images(mode, T, dims, monkeypatch):
+    """bitmap_kernel's workgroups loop over images and fetch the ranges two images ahead into LDS (global_load_lds), issued
+    by half of the waves while the others work.  A launch of 3 workgroups for 41 images makes every workgroup draw 13-14 of
+    them (F110_BM_GRID: the launch's workgroup count; normally one per resident slot): every image, the first, the prefetched
+    ones and the last two (nothing left to prefetch), `==` the oracle's -- fp64 scans (two loads per range) and fp32."""
+    from oracle import bitmap as ob
+    from red_gym_amd.lidar import LidarBitmap
+    nb = 2048 if T > 1079 else 1080
+    scans = np.concatenate([_scans(17, nb=nb, seed=31, kind='track'), _scans(12, nb=nb, seed=32, kind='noise'),
+                            _scans(6, nb=nb, seed=33, kind='far'), _scans(6, nb=nb, seed=34, kind='tiny')])
+    scans = scans[np.random.default_rng(5).permutation(len(scans))]
+    kw = dict(bg_color='black', draw_mode=mode, target_beam_count=T, output_image_dims=dims)
+    want = ob.lidar_to_bitmap(scans, **kw)
+    r = LidarBitmap(nb, **kw)
+    for grid in ('3', '7', '41', None):
+        if grid is None:
+            monkeypatch.delenv('F110_BM_GRID', raising=False)
+        else:
+            monkeypatch.setenv('F110_BM_GRID', grid)
+        got = r(torch.as_tensor(scans, device='cuda')).cpu().numpy()
+        bad = np.argwhere(got != want)
+        assert bad.size == 0, (grid, 'first mismatches (img, row, col): %s' % bad[:5].tolist())
+        s32 = scans.astype(np.float32)
+        got32 = r(torch.as_tensor(s32, device='cuda')).cpu().numpy()
+        assert np.array_equal(got32, ob.lidar_to_bitmap(s32.astype(np.float64), **kw)), grid
+    r.close()
+
+
 def test_bitmap_full_batch_finishes_and_is_deterministic():
     from red_gym_amd.lidar import LidarBitmap
     n = 8192
