@@ -330,7 +330,9 @@ __device__ inline double bm_range(const BitmapArgs &a, int img, int beam)
 __device__ inline void bm_load_to_lds(const unsigned *src, const unsigned *lds_dst_wave /* the wave's lane 0 slot; uniform */)
 {
     const unsigned m0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_dst_wave); // low word of a flat LDS address = LDS offset
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" : : "v"(src), "s"(m0) : "memory", "m0");
+    unsigned keep; // (M0 is the compiler's own register: handed back as it was)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(m0) : "memory");
 }
 __device__ inline int bm_prefetch(const BitmapArgs &a, int img, const unsigned short *beams, unsigned *stage, int tid)
 {
