@@ -72,6 +72,9 @@ constexpr int BM_DIRECT = F110_BM_DIRECT;
 #ifndef F110_BM_X
 #define F110_BM_X 0   // experiments only (tools/build_variant.sh): 1 = no segments drawn, 2 = no parity pass, 4 = no points
 #endif
+#ifndef F110_BM_PRIO
+#define F110_BM_PRIO 1
+#endif
 #ifndef F110_BM_MIN_SHARE
 #define F110_BM_MIN_SHARE 1
 #endif
@@ -396,6 +399,15 @@ static __global__ __launch_bounds__(256) void bitmap_points_kernel(BitmapArgs a,
 #endif
 
 #if defined(F110_UNIT_CONSUMERS)
+// The image workgroup g draws in round `it` of a launch of `grid` workgroups; a value >= n: none (and none in later rounds).
+// (Rotating the rounds' slots, so that a workgroup sees every kind of image, changes nothing: the spread of the workgroups'
+// lives -- 620 to 980 us in one launch -- follows their dispatch order, not their images; profiles/r05_bitmap.txt.)
+__host__ __device__ inline int bm_image_of(int g, int it, int grid, int n)
+{
+    const long long i = (long long)it * grid + g;
+    return i < n ? (int)i : n;
+}
+
 // WPE: waves per SIMD the registers are budgeted for; AHEAD: ranges fetched two images ahead (see bm_fetch_ahead)
 template <int WPE, bool AHEAD>
 static __global__ __launch_bounds__(BM_THREADS) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void bitmap_kernel(BitmapArgs a)
@@ -428,7 +440,7 @@ static __global__ __launch_bounds__(BM_THREADS) __attribute__((amdgpu_waves_per_
     const int cx = rows / 2, cy = cols / 2; // lidar.py:75: center = (dims[0]//2, dims[1]//2), used as (x, y)
     if (tid0 < 64) s_fdx[tid0] = (tid0 & 7) ? ((tid0 >> 3) << BM_XY_SHIFT) / (tid0 & 7) : 0;
 
-    // A workgroup draws images blockIdx.x, blockIdx.x + gridDim.x, ... (the launch holds as many workgroups as the GPU runs
+    // A workgroup draws one image per round of the launch (bm_image_of; the launch holds as many workgroups as the GPU runs
     // at once).  What an image needs from memory -- its T ranges, an HBM gather -- is fetched TWO images ahead, into LDS:
     // with one image per workgroup 6 of a workgroup's 15 us went into waiting for these loads, and merely ISSUING them
     // stalls a wave for ~1.7 us while every CU's memory pipe is full of the other images' pixels.  So the loads are issued
@@ -444,11 +456,12 @@ static __global__ __launch_bounds__(BM_THREADS) __attribute__((amdgpu_waves_per_
                 const double2 c = make_double2(a.cosv[k], a.sinv[k]);
                 beams[k] = (unsigned short)b;
                 cs[k] = c;
-                if ((int)blockIdx.x < a.n && !(F110_BM_X & 4)) pts[k] = bm_point_at(a.scale, bm_range(a, blockIdx.x, b), c.x, c.y, cx, cy);
+                if (!(F110_BM_X & 4)) pts[k] = bm_point_at(a.scale, bm_range(a, blockIdx.x, b), c.x, c.y, cx, cy); // (round 0: image g)
             }
         }
         bm_barrier(); // (beams staged)
-        if ((int)(blockIdx.x + gridDim.x) < a.n && !(F110_BM_X & 4)) (void)bm_prefetch(a, blockIdx.x + gridDim.x, beams, stage + stage_words, tid0);
+        const int img1 = bm_image_of(blockIdx.x, 1, gridDim.x, a.n);
+        if (img1 < a.n && !(F110_BM_X & 4)) (void)bm_prefetch(a, img1, beams, stage + stage_words, tid0);
     }
     int it = 0;
     // (!AHEAD: one image per workgroup, the launch has a workgroup per image -- the loop is left after one pass, and the
@@ -459,12 +472,20 @@ static __global__ __launch_bounds__(BM_THREADS) __attribute__((amdgpu_waves_per_
     // then recomputed per image instead of being carried in registers around the whole loop -- the kernel has 64)
     int tid = tid0;
     asm volatile("" : "+v"(tid));
+#if F110_BM_PRIO
+    // The CU's arbiter serves the oldest wave first: of the three workgroups that share a CU for the whole launch, the one
+    // dispatched first would draw its images a third faster than the last.  The user priority goes round instead.
+    if (AHEAD) {
+        const int turn = ((int)(blockIdx.x * 3u / gridDim.x) + it) % 3;
+        if (turn == 0) __builtin_amdgcn_s_setprio(2); else if (turn == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+    }
+#endif
 #if defined(F110_BM_TIMELINE)
     if (tid < BM_TL) s_tl[tid] = 0;
     bm_barrier();
 #endif
     BM_STAMP(0);
-    const int img_next = img + (int)gridDim.x, img_next2 = img_next + (int)gridDim.x;
+    const int img_next = AHEAD ? bm_image_of(blockIdx.x, it + 1, gridDim.x, a.n) : a.n, img_next2 = AHEAD ? bm_image_of(blockIdx.x, it + 2, gridDim.x, a.n) : a.n;
     if (!AHEAD)
         for (int k = tid; k < ((F110_BM_X & 4) ? 0 : T); k += BM_THREADS) pts[k] = bm_point(a, img, k, cx, cy);
     // zero both planes (contiguous, each on a 16-byte boundary: 16 bytes per store)
@@ -556,28 +577,25 @@ static __global__ __launch_bounds__(BM_THREADS) __attribute__((amdgpu_waves_per_
     const int n_in = s_nq[0], nq = n_in + s_nq[1];
     for (int q0 = 0; q0 < nq; q0 += qcap) {
         const int nr = min(qcap, nq - q0);
-        // records: the inside segments take the short 32-bit set-up, the ones that need clipLine's 64-bit arithmetic and
-        // fp64 divisions the long one -- in separate loops, so that a wave runs the long form only if it holds such a segment
-        for (int pass = 0; pass < 2; pass++) {
-            const int j0 = pass == 0 ? q0 : max(q0, n_in), j1 = pass == 0 ? min(q0 + nr, n_in) : q0 + nr;
-            const int t2 = (tid - pass * 64) & (BM_THREADS - 1); // (the two forms start on different waves: side by side)
-            for (int j = j0 + t2; j < j1; j += BM_THREADS) {
-                const int i = pass == 0 ? queue[j] : queue[T - 1 - (j - n_in)];
-                const int2 p1 = pts[i];
-                const int2 p0 = mode == BM_RAYS ? make_int2(cx, cy) : pts[i == 0 ? T - 1 : i - 1];
-                EdgeRec r;
-                start[j - q0] = pass == 0 ? bm_edge_setup_inside(mode, p0, p1, r) : bm_edge_setup(mode, rows, cols, p0, p1, r);
-                recs[j - q0] = r;
-            }
-        }
-        bm_barrier();
-        BM_STAMP(3); // records
-        // exclusive prefix of the item counts, in place
+        // records (the inside segments take the short 32-bit set-up, the ones that need clipLine's 64-bit arithmetic and
+        // fp64 divisions the long one) and the exclusive prefix of their item counts
         int total;
         if (nr <= 64) {
-            // (the usual case of FILL / POLYGON: a few dozen queued segments -- one wave, no block-wide scan)
+            // (the usual case of FILL / POLYGON: a few dozen queued segments -- one wave sets them up and scans the counts
+            // in its registers: one barrier, no block-wide scan)
             if (tid < 64) {
-                const int v = tid < nr ? start[tid] : 0;
+                int v = 0;
+                if (tid < nr) {
+                    const int j = q0 + tid;
+                    const bool in = j < n_in;
+                    const int i = in ? queue[j] : queue[T - 1 - (j - n_in)];
+                    const int2 p1 = pts[i];
+                    const int2 p0 = mode == BM_RAYS ? make_int2(cx, cy) : pts[i == 0 ? T - 1 : i - 1];
+                    EdgeRec r;
+                    if (in) v = bm_edge_setup_inside(mode, p0, p1, r);
+                    else v = bm_edge_setup(mode, rows, cols, p0, p1, r);
+                    recs[tid] = r;
+                }
                 int incl = v;
                 for (int off = 1; off < 64; off <<= 1) {
                     const int t = __shfl_up(incl, off, 64);
@@ -587,8 +605,23 @@ static __global__ __launch_bounds__(BM_THREADS) __attribute__((amdgpu_waves_per_
                 if (tid == 63) start[nr] = incl;
             }
             bm_barrier();
+            BM_STAMP(3); // records + prefix
             total = start[nr];
         } else {
+            // (separate loops, so that a wave runs the long form only if it holds such a segment)
+            for (int pass = 0; pass < 2; pass++) {
+                const int j0 = pass == 0 ? q0 : max(q0, n_in), j1 = pass == 0 ? min(q0 + nr, n_in) : q0 + nr;
+                for (int j = j0 + tid; j < j1; j += BM_THREADS) {
+                    const int i = pass == 0 ? queue[j] : queue[T - 1 - (j - n_in)];
+                    const int2 p1 = pts[i];
+                    const int2 p0 = mode == BM_RAYS ? make_int2(cx, cy) : pts[i == 0 ? T - 1 : i - 1];
+                    EdgeRec r;
+                    start[j - q0] = pass == 0 ? bm_edge_setup_inside(mode, p0, p1, r) : bm_edge_setup(mode, rows, cols, p0, p1, r);
+                    recs[j - q0] = r;
+                }
+            }
+            bm_barrier();
+            BM_STAMP(3); // records
             // thread t owns records t*per .. t*per + per - 1
             const int per = (nr + BM_THREADS - 1) / BM_THREADS;
             int cnt[BM_PER_MAX], local = 0;
@@ -805,7 +838,7 @@ static __global__ __launch_bounds__(BM_THREADS) __attribute__((amdgpu_waves_per_
 #endif
     if (!AHEAD) break;
     bm_barrier(); // the planes, the records' place (grey-level table) and the points are the next image's from here
-    img += (int)gridDim.x; it++;
+    img = img_next; it++;
     } while (img < a.n);
 }
 #endif

@@ -319,6 +319,27 @@ extern "C" int f110_bitmap_render(f110_bitmap *b, const void *scans, int32_t sca
         }
         fprintf(stderr, "bitmap timeline (%lld images, 100 MHz ticks -> us): launch %.1f us;", (long long)n, (t1 - t0) / 100.0);
         for (int j = 0; j < 8; j++) fprintf(stderr, " %s %.2f", names[j], sum[j] / n / 100.0);
+        // between a workgroup's images (last stamp of one -> first stamp of the next) and a workgroup's life (first stamp of
+        // its first image -> last stamp of its last one); workgroup g draws bm_image_of(g, round, grid, n)
+        double gap = 0, life = 0, life_min = 1e30, life_max = 0, first = 0, first_max = 0; long long gaps = 0;
+        const bool ahead = bm_fetch_ahead(a.mode, a.channels);
+        for (int64_t g = 0; g < grid; g++) {
+            int64_t prev = g, last = g;
+            for (int it = 1; ahead; it++) {
+                const int64_t i = bm_image_of((int)g, it, (int)grid, (int)n);
+                if (i >= n) break;
+                gap += (double)(h[(size_t)i * BM_TL] - h[(size_t)prev * BM_TL + 7]); gaps++;
+                prev = last = i;
+            }
+            const double l = (double)(h[(size_t)last * BM_TL + 7] - h[(size_t)g * BM_TL]), f = (double)(h[(size_t)g * BM_TL] - t0);
+            life += l; life_min = std::min(life_min, l); life_max = std::max(life_max, l); first += f; first_max = std::max(first_max, f);
+        }
+        if (gaps) fprintf(stderr, " | between images %.2f (grid %lld)", gap / gaps / 100.0, (long long)grid);
+        if (const char *dump = getenv("F110_BM_TL_DUMP")) { // raw stamps for offline analysis
+            if (FILE *f = fopen(dump, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+        }
+        const double gn = (double)grid;
+        fprintf(stderr, " | workgroup life mean %.1f min %.1f max %.1f, first stamp after launch start mean %.1f max %.1f", life / gn / 100.0, life_min / 100.0, life_max / 100.0, first / gn / 100.0, first_max / 100.0);
         fprintf(stderr, "\n");
     }
 #endif
