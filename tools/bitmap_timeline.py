@@ -1,6 +1,13 @@
+"""Where a bitmap_kernel workgroup's time goes (round 5, profiles/r05_bitmap.txt).
+    tools/build_variant.sh bmtl -DF110_BM_TIMELINE            # VARIANT_DIR=variants_ship to take it to the GPU box
+    F110_LIB=build_variants/bmtl.so F110_LIB_OLDER=1 F110_BM_TL_DUMP=/tmp/tl.bin python tools/bench_bitmap.py --reps 1
+    python tools/bitmap_timeline.py /tmp/tl.bin [workgroups of the launch, default 768]
+The diagnostics build stamps the 100 MHz clock at every stage boundary of every image ([n][10] uint64) and prints the mean
+stage times itself; this script reads the dump: the lives of the launch's workgroups (workgroup g draws images g, g + grid,
+...), their spread, and whether the slow ones are slow because of their images or because of where they sit."""
 import numpy as np, sys
 h = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 10).astype(np.int64)
-n = len(h); grid = 768
+n = len(h); grid = int(sys.argv[2]) if len(sys.argv) > 2 else 768
 t0 = h[:, 0].min()
 life = []; busy = []
 for g in range(grid):
